@@ -1,0 +1,172 @@
+// kernels.hpp -- launch interface between the rx context (rx.cpp) and the
+// gfx950 kernels (kernels.hip).  All pointers are device pointers unless
+// noted.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ookd {
+
+constexpr int kMaxStages = 8;
+constexpr int kTapChunk = 32;           // taps are padded to a multiple of this
+constexpr int kFirThreads = 256;
+constexpr int kFirR = 16;               // outputs per lane in the 1-stage kernel
+constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
+constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
+constexpr int kBlockWords = 64;         // one edge block = 64 words = 4096 bits
+constexpr int kPayloadWords = 5;        // 4 x u64 payload + 1 spare (bit index == max_bits)
+constexpr int kMaxStates = 64;
+constexpr int kMaxTriggers = 256;
+
+// ---- front end -------------------------------------------------------------
+
+struct FirStageDev {
+    uint32_t decim;
+    uint32_t ntaps;         // true tap count
+    uint32_t ntaps_pad;     // padded to kTapChunk (1-stage kernel)
+    uint32_t tap_off;       // offset into the taps array (floats)
+};
+
+struct FrontParams {
+    const int16_t *iq;          // captures, interleaved I,Q
+    const float *iq_f32;        // alternative float2 input (streaming FIR API)
+    uint64_t cap_stride;        // samples between consecutive captures
+    uint64_t n_valid;           // samples present per capture; beyond: zeros
+    uint64_t n_in;              // samples consumed per capture (padded)
+    uint64_t n_out;             // decimated outputs per capture
+    uint64_t origin;            // global index of local input sample 0
+    const int16_t *halo;        // samples preceding sample 0 (newest last) or null
+    const float *halo_f32;
+    uint32_t halo_len;
+    uint32_t num_stages;        // 0 = no filter
+    FirStageDev stage[kMaxStages];
+    const float *taps;          // all stages, 1-stage kernel: zero padded
+    uint64_t *bits;             // [captures][words_per_cap]
+    uint64_t words_per_cap;     // multiple of kBlockWords, tile-padded
+    float *fir_out;             // optional float2 [captures][n_out]
+    float p_star;               // smallest power whose sqrtf >= threshold
+    float p_lo, p_hi;           // guard band (fast mode): p<p_lo => 0, p>=p_hi => 1
+    unsigned long long *recompute_count;
+};
+
+hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
+                        hipStream_t stream);
+// Generic multi-stage kernel regardless of shape (cross-check / streaming FIR).
+hipError_t launch_front_generic(const FrontParams &p, uint32_t num_captures,
+                                hipStream_t stream);
+size_t generic_lds_bytes(const FrontParams &p);
+
+// ---- edges -----------------------------------------------------------------
+
+struct EdgeParams {
+    const uint64_t *bits;
+    uint64_t words_per_cap;
+    uint32_t num_captures;
+    uint32_t blocks_per_cap;    // words_per_cap / kBlockWords
+    uint32_t *blk_count;        // [captures * blocks_per_cap]
+    uint32_t *blk_offset;       // exclusive prefix, same size + 1
+    uint64_t *edges;            // capture-local decimated indices
+    uint64_t edge_capacity;
+    uint32_t *overflow;         // set to 1 when total edges > capacity
+};
+
+hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);
+
+// ---- state machine ---------------------------------------------------------
+
+struct FsmTablesDev {
+    uint32_t num_states, max_bits, num_triggers, pad;
+    uint64_t state_kmin[kMaxStates], state_kmax[kMaxStates], state_kto[kMaxStates];
+    uint32_t trig_begin[kMaxStates + 1];
+    uint64_t trig_kmin[kMaxTriggers], trig_kmax[kMaxTriggers];
+    uint32_t trig_next[kMaxTriggers];
+    uint8_t trig_cond[kMaxTriggers], trig_action[kMaxTriggers];
+};
+
+struct FsmStateDev {            // same layout as ookd_fsm_state
+    uint32_t cur, nbits;
+    uint64_t k;
+    uint32_t prev, pad;
+    uint64_t data[kPayloadWords];
+};
+static_assert(sizeof(FsmStateDev) == 64, "FsmStateDev layout");
+
+struct MsgDev {                 // same layout as ookd_message
+    uint32_t capture, reserved;
+    uint64_t sample;
+    uint64_t payload[4];
+};
+static_assert(sizeof(MsgDev) == 48, "MsgDev layout");
+
+struct FsmParams {
+    const FsmTablesDev *tables;
+    const uint64_t *bits;
+    uint64_t words_per_cap;
+    const uint64_t *edges;
+    const uint32_t *blk_offset;
+    uint32_t blocks_per_cap;
+    uint32_t num_captures;
+    uint64_t n_out;             // decimated samples per capture
+    uint32_t spb;               // input samples per buffer
+    uint32_t total_decim;
+    uint32_t seg_buffers;       // buffers per segment
+    uint32_t segs_per_cap;
+    uint32_t msg_slots, err_slots;
+    FsmStateDev *state_in;      // [segs]
+    FsmStateDev *state_out;     // [2][segs] ping-pong by iteration parity
+    MsgDev *seg_msgs;           // [segs][msg_slots]
+    uint32_t *seg_msg_count;    // [segs]
+    uint64_t *seg_errs;         // [segs][err_slots]
+    uint32_t *seg_err_count;    // [segs]
+    uint32_t *changed;          // [iterations]
+    uint32_t *flags;            // bit0: message slot overflow
+    // compaction
+    MsgDev *msgs;               // [msg_capacity]
+    uint64_t msg_capacity;
+    uint64_t *totals;           // [0] messages, [1] errors
+};
+
+hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state,
+                              hipStream_t stream);
+hipError_t launch_fsm_iteration(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
+                                hipStream_t stream);
+hipError_t launch_fsm_gather(const FsmParams &p, uint32_t final_parity, hipStream_t stream);
+
+// ---- unpack (backend rx) ----------------------------------------------------
+hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream);
+
+// ---- synthetic generator ------------------------------------------------------
+
+struct SynthRun {               // one constant-envelope run of the capture
+    uint64_t start;             // first sample of the run
+    int16_t i_level, q_level;   // carrier-rotated on level (0,0 when off)
+    uint32_t pad;
+};
+
+// Same integer function on host and device: sample = level + noise.
+__host__ __device__ inline uint64_t synth_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__host__ __device__ inline void synth_noise(uint64_t seed, uint64_t idx, uint32_t amp,
+                                            int &ni, int &nq) {
+    if (amp == 0) {
+        ni = nq = 0;
+        return;
+    }
+    const uint64_t h = synth_mix(seed ^ (idx * 0xD1342543DE82EF95ull));
+    const uint32_t span = 2 * amp + 1;
+    ni = (int)(((h & 0xffffffffull) * span) >> 32) - (int)amp;
+    nq = (int)(((h >> 32) * span) >> 32) - (int)amp;
+}
+
+hipError_t launch_synth(const SynthRun *runs, uint64_t num_runs, uint64_t seed,
+                        uint32_t noise, uint64_t first, uint64_t count, int16_t *iq,
+                        hipStream_t stream);
+
+}  // namespace ookd

@@ -1,0 +1,786 @@
+// rx.cpp -- rx context: HBM buffers, kernel sequencing, C ABI of the fused
+// demodulation entry (replaces the body of the reference loop,
+// src/ookiedokie.c:243-288, for whole captures resident in HBM).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+using namespace ookd;
+
+namespace {
+
+#define HIPCHK(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            set_error("HIP error %d (%s) at %s:%d: %s", (int)_e,                  \
+                      hipGetErrorString(_e), __FILE__, __LINE__, #expr);          \
+            return OOKD_ERR_HIP;                                                  \
+        }                                                                         \
+    } while (0)
+
+constexpr uint32_t kIterBatch = 4;      // FSM fix-point rounds queued per host sync
+constexpr uint32_t kMaxIter = 1u << 16;
+constexpr uint64_t kHostMsgFirst = 2048;    // messages copied with the header
+
+struct ResultHeader {
+    uint32_t changed[kIterBatch];
+    uint32_t flags;
+    uint32_t edge_overflow;
+    uint64_t totals[2];
+    unsigned long long recompute;
+    uint32_t total_edges;
+    uint32_t pad;
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        n = count;
+        if (count == 0) return OOKD_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            p = nullptr;
+            return OOKD_ERR_NOMEM;
+        }
+        return OOKD_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// smallest float p with sqrtf(p) >= thr  (SURVEY.md hard part 3)
+float power_threshold(float thr) {
+    if (std::isnan(thr)) return NAN;
+    if (thr <= 0.0f) return 0.0f;
+    if (std::isinf(thr)) return INFINITY;
+    float p = (float)((double)thr * (double)thr);
+    while (p > 0.0f && sqrtf(nextafterf(p, 0.0f)) >= thr) p = nextafterf(p, 0.0f);
+    while (!std::isinf(p) && sqrtf(p) < thr) p = nextafterf(p, INFINITY);
+    return p;
+}
+
+// Guard band for the fused-multiply-add FIR (1 stage): any sample whose
+// FMA-computed power lies in [p_lo, p_hi) is recomputed in reference order.
+// e bounds |y_fma - y_ref| per component: both chains are within
+// gamma_T * sum|h||x| of the exact sum (one rounding per step for fma, two
+// for mul+add), inputs are bounded by 32768/2048 = 16.
+void guard_band(const std::vector<float> &taps, float p_star, float &p_lo, float &p_hi) {
+    if (std::isnan(p_star) || std::isinf(p_star) || p_star <= 0.0f) {
+        p_lo = p_hi = p_star;
+        return;
+    }
+    const double u = std::ldexp(1.0, -24);
+    double S = 0.0;
+    for (float t : taps) S += std::fabs((double)t);
+    const double T = (double)taps.size();
+    const double e = 2.2 * (T + 1.0) * u * S * 16.0 + T * std::ldexp(1.0, -140);
+    const double P = (double)p_star;
+    // |p_ref - p_fma| <= m(p) = 3.003*e*sqrt(p) + 3e^2 + 6u*p
+    // upper edge: smallest s = sqrt(p) with (1-6u)s^2 - 3.003e s - (3e^2 + P) >= 0
+    {
+        const double a = 1.0 - 6.0 * u, b = 3.003 * e, c = 3.0 * e * e + P;
+        double s = (b + std::sqrt(b * b + 4.0 * a * c)) / (2.0 * a);
+        double ph = s * s * (1.0 + 1e-6);
+        ph = std::max(ph, 4.0 * e * e);     // p - m(p) is increasing beyond ~2.3e^2
+        float f = (float)ph;
+        if ((double)f < ph) f = nextafterf(f, INFINITY);
+        f = nextafterf(f, INFINITY);
+        p_hi = std::max(f, p_star);
+    }
+    // lower edge: largest s with (1+6u)s^2 + 3.003e s + 3e^2 - P < 0
+    {
+        const double a = 1.0 + 6.0 * u, b = 3.003 * e, c = 3.0 * e * e - P;
+        if (c >= 0.0) {
+            p_lo = 0.0f;
+        } else {
+            double s = (-b + std::sqrt(b * b - 4.0 * a * c)) / (2.0 * a);
+            double pl = s > 0.0 ? s * s * (1.0 - 1e-6) : 0.0;
+            float f = (float)pl;
+            if ((double)f > pl) f = nextafterf(f, 0.0f);
+            f = nextafterf(f, 0.0f);
+            p_lo = std::max(f, 0.0f);
+        }
+    }
+}
+
+uint64_t gcd64(uint64_t a, uint64_t b) {
+    while (b) {
+        uint64_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+}  // namespace
+
+struct ookd_rx {
+    ookd_rx_config cfg{};
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+
+    // filter
+    uint32_t num_stages = 0;
+    FirStageDev stage[kMaxStages]{};
+    uint32_t total_decim = 1;
+    uint64_t halo_needed = 0;
+    std::vector<float> taps0;       // stage-0 true taps (guard band)
+    DevBuf<float> d_taps;
+    float p_star = 0, p_lo = 0, p_hi = 0;
+    bool exact = false;
+
+    // device (state machine)
+    bool have_fsm = false;
+    uint32_t num_bits = 0;
+    DevBuf<FsmTablesDev> d_tables;
+
+    // capacity
+    uint64_t max_samples = 0;
+    uint32_t max_captures = 1;
+    uint64_t max_n_in = 0, max_n_out = 0, max_words = 0;
+    uint32_t max_blocks = 0, max_segs_per_cap = 0;
+    uint32_t seg_buffers = 0, msg_slots = 0, err_slots = 0;
+    uint64_t edge_capacity = 0, msg_capacity = 0;
+
+    DevBuf<uint64_t> d_bits;
+    DevBuf<float> d_fir;
+    DevBuf<int16_t> d_halo;
+    DevBuf<uint32_t> d_blk_count, d_blk_offset;
+    DevBuf<uint64_t> d_edges;
+    DevBuf<FsmStateDev> d_state_in, d_state_out;
+    DevBuf<MsgDev> d_seg_msgs, d_msgs;
+    DevBuf<uint32_t> d_seg_msg_count, d_seg_err_count;
+    DevBuf<uint64_t> d_seg_errs;
+    DevBuf<ResultHeader> d_hdr;
+    DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
+
+    ResultHeader *h_hdr = nullptr;  // pinned
+    MsgDev *h_msgs = nullptr;       // pinned, msg_capacity
+    uint64_t num_msgs = 0;
+
+    // geometry of the last run
+    uint32_t run_caps = 0;
+    uint64_t run_n_valid = 0, run_n_in = 0, run_n_out = 0, run_words = 0;
+    uint32_t run_blocks = 0, run_segs_per_cap = 0;
+    uint32_t iter_next = 0;         // next FSM iteration number (parity continues)
+    uint32_t final_parity = 0;
+    ookd_rx_stats stats{};
+
+    ~ookd_rx() {
+        (void)hipSetDevice(dev);
+        d_taps.release();
+        d_tables.release();
+        d_bits.release();
+        d_fir.release();
+        d_halo.release();
+        d_blk_count.release();
+        d_blk_offset.release();
+        d_edges.release();
+        d_state_in.release();
+        d_state_out.release();
+        d_seg_msgs.release();
+        d_msgs.release();
+        d_seg_msg_count.release();
+        d_seg_err_count.release();
+        d_seg_errs.release();
+        d_hdr.release();
+        d_stage_in.release();
+        if (h_hdr) (void)hipHostFree(h_hdr);
+        if (h_msgs) (void)hipHostFree(h_msgs);
+        for (auto &e : ev) {
+            if (e) (void)hipEventDestroy(e);
+        }
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+
+    void geometry(uint64_t n_valid, bool pad_to_buffer, uint64_t &n_in, uint64_t &n_out,
+                  uint64_t &words, uint32_t &blocks, uint32_t &segs) const {
+        const uint64_t spb = cfg.samples_per_buffer;
+        n_in = pad_to_buffer ? ((n_valid + spb - 1) / spb) * spb : n_valid;
+        n_out = n_in / total_decim;
+        const uint64_t tiles = (n_out + kFirTile - 1) / kFirTile;
+        words = tiles * (kFirTile / 64);
+        blocks = (uint32_t)(words / kBlockWords);
+        const uint64_t nbuf = (n_in + spb - 1) / spb;
+        segs = (uint32_t)((nbuf + seg_buffers - 1) / seg_buffers);
+        if (segs == 0 && n_out > 0) segs = 1;
+    }
+
+    FrontParams front_params(const void *d_iq, uint64_t stride) const {
+        FrontParams p{};
+        p.iq = static_cast<const int16_t *>(d_iq);
+        p.cap_stride = stride;
+        p.n_valid = run_n_valid;
+        p.n_in = run_n_in;
+        p.n_out = run_n_out;
+        p.num_stages = num_stages;
+        for (uint32_t s = 0; s < num_stages; ++s) p.stage[s] = stage[s];
+        p.taps = d_taps.p;
+        p.bits = d_bits.p;
+        p.words_per_cap = run_words;
+        p.fir_out = (cfg.flags & OOKD_RX_KEEP_FIR) ? d_fir.p : nullptr;
+        p.p_star = p_star;
+        p.p_lo = p_lo;
+        p.p_hi = p_hi;
+        p.recompute_count = &d_hdr.p->recompute;
+        return p;
+    }
+
+    EdgeParams edge_params() const {
+        EdgeParams e{};
+        e.bits = d_bits.p;
+        e.words_per_cap = run_words;
+        e.num_captures = run_caps;
+        e.blocks_per_cap = run_blocks;
+        e.blk_count = d_blk_count.p;
+        e.blk_offset = d_blk_offset.p;
+        e.edges = d_edges.p;
+        e.edge_capacity = edge_capacity;
+        e.overflow = &d_hdr.p->edge_overflow;
+        return e;
+    }
+
+    FsmParams fsm_params() const {
+        FsmParams f{};
+        f.tables = d_tables.p;
+        f.bits = d_bits.p;
+        f.words_per_cap = run_words;
+        f.edges = d_edges.p;
+        f.blk_offset = d_blk_offset.p;
+        f.blocks_per_cap = run_blocks;
+        f.num_captures = run_caps;
+        f.n_out = run_n_out;
+        f.spb = cfg.samples_per_buffer;
+        f.total_decim = total_decim;
+        f.seg_buffers = seg_buffers;
+        f.segs_per_cap = run_segs_per_cap;
+        f.msg_slots = msg_slots;
+        f.err_slots = err_slots;
+        f.state_in = d_state_in.p;
+        f.state_out = d_state_out.p;
+        f.seg_msgs = d_seg_msgs.p;
+        f.seg_msg_count = d_seg_msg_count.p;
+        f.seg_errs = d_seg_errs.p;
+        f.seg_err_count = d_seg_err_count.p;
+        f.changed = d_hdr.p->changed;
+        f.flags = &d_hdr.p->flags;
+        f.msgs = d_msgs.p;
+        f.msg_capacity = msg_capacity;
+        f.totals = d_hdr.p->totals;
+        return f;
+    }
+
+    int front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
+                        uint32_t halo_len);
+    int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
+    int fetch_results();
+};
+
+int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
+                             uint32_t halo_len) {
+    HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    FrontParams fp = front_params(d_iq, stride);
+    fp.halo = d_halo_ptr;
+    fp.halo_len = halo_len;
+    HIPCHK(hipEventRecord(ev[0], stream));
+    HIPCHK(launch_front(fp, run_caps, exact, stream));
+    HIPCHK(hipEventRecord(ev[1], stream));
+    if (run_n_out > 0) HIPCHK(launch_edges(edge_params(), stream));
+    return OOKD_OK;
+}
+
+// Runs segment-parallel state machine rounds until no segment's incoming
+// state changes.  fresh: (re)initialise every segment's assumed state.
+int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first) {
+    if (!have_fsm || run_n_out == 0) {
+        HIPCHK(hipEventRecord(ev[2], stream));
+        return OOKD_OK;
+    }
+    const FsmParams fp = fsm_params();
+    if (fresh) {
+        HIPCHK(launch_fsm_prepare(fp, first, stream));
+        iter_next = 0;
+    } else if (force_first) {
+        // refine: new incoming state for segment 0 of the (single) capture
+        HIPCHK(hipMemcpyAsync(d_state_in.p, first, sizeof(FsmStateDev), hipMemcpyHostToDevice, stream));
+    }
+    uint32_t rounds = 0;
+    uint32_t mode = fresh ? 0u : (force_first ? 2u : 1u);
+    for (;;) {
+        HIPCHK(hipMemsetAsync(d_hdr.p->changed, 0, sizeof(uint32_t) * kIterBatch, stream));
+        const uint32_t batch_mode0 = mode;
+        for (uint32_t i = 0; i < kIterBatch; ++i) {
+            HIPCHK(launch_fsm_iteration(fp, iter_next & 1u, mode, i, stream));
+            iter_next++;
+            mode = 1;
+        }
+        HIPCHK(hipMemcpyAsync(h_hdr->changed, d_hdr.p->changed, sizeof(uint32_t) * kIterBatch,
+                              hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        rounds += kIterBatch;
+        // converged once an incremental round reran nothing (a mode-0 round
+        // reruns everything and reports no count; a mode-2 round counts the
+        // forced first segments)
+        bool conv = false;
+        for (uint32_t i = 0; i < kIterBatch && !conv; ++i) {
+            const bool incremental = !(i == 0 && batch_mode0 != 1u);
+            if (incremental && h_hdr->changed[i] == 0) conv = true;
+        }
+        if (conv) break;
+        if (rounds > kMaxIter) {
+            set_error("state machine fix-point did not converge in %u rounds", rounds);
+            return OOKD_ERR_ARG;
+        }
+    }
+    final_parity = (iter_next - 1) & 1u;
+    stats.fsm_iterations = rounds;
+    HIPCHK(launch_fsm_gather(fp, final_parity, stream));
+    HIPCHK(hipEventRecord(ev[2], stream));
+    return OOKD_OK;
+}
+
+int ookd_rx::fetch_results() {
+    HIPCHK(hipMemcpyAsync(h_hdr, d_hdr.p, sizeof(ResultHeader), hipMemcpyDeviceToHost, stream));
+    const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
+    if (have_fsm && run_n_out > 0) {
+        HIPCHK(hipMemcpyAsync(h_msgs, d_msgs.p, first * sizeof(MsgDev), hipMemcpyDeviceToHost, stream));
+    }
+    uint32_t total_edges = 0;
+    if (run_n_out > 0) {
+        HIPCHK(hipMemcpyAsync(&h_hdr->total_edges, d_blk_offset.p + (size_t)run_caps * run_blocks,
+                              sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    total_edges = run_n_out > 0 ? h_hdr->total_edges : 0;
+    num_msgs = 0;
+    stats.num_edges = total_edges;
+    stats.num_messages = 0;
+    stats.num_errors = 0;
+    stats.guard_recomputes = h_hdr->recompute;
+    stats.input_samples = run_n_in;
+    stats.decimated_samples = run_n_out;
+    stats.num_segments = run_caps * run_segs_per_cap;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats.fir_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
+    if (h_hdr->edge_overflow) {
+        set_error("edge list overflow: %u level changes found, capacity %llu "
+                  "(raise ookd_rx_config.edge_capacity)",
+                  total_edges, (unsigned long long)edge_capacity);
+        return OOKD_ERR_CAPACITY;
+    }
+    if (have_fsm && run_n_out > 0) {
+        if (h_hdr->flags & 1u) {
+            set_error("a state machine segment produced more than %u messages "
+                      "(raise ookd_rx_config.message_slots)", msg_slots);
+            return OOKD_ERR_CAPACITY;
+        }
+        const uint64_t total = h_hdr->totals[0];
+        if (total > msg_capacity) {
+            set_error("message list overflow: %llu messages, capacity %llu",
+                      (unsigned long long)total, (unsigned long long)msg_capacity);
+            return OOKD_ERR_CAPACITY;
+        }
+        if (total > first) {
+            HIPCHK(hipMemcpy(h_msgs + first, d_msgs.p + first, (total - first) * sizeof(MsgDev),
+                             hipMemcpyDeviceToHost));
+        }
+        num_msgs = total;
+        stats.num_messages = total;
+        stats.num_errors = h_hdr->totals[1];
+    }
+    return OOKD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
+                        const ookd_device *device) {
+    clear_error();
+    if (!cfg || cfg->samples_per_buffer == 0 || cfg->max_samples == 0) {
+        set_error("ookd_rx_create: samples_per_buffer and max_samples must be non-zero");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: libookiedokie_amd has no CPU fallback");
+        return nullptr;
+    }
+    if (cfg->hip_device < 0 || cfg->hip_device >= ndev) {
+        set_error("hip_device %d out of range (%d devices)", cfg->hip_device, ndev);
+        return nullptr;
+    }
+    std::unique_ptr<ookd_rx> rx(new ookd_rx());
+    rx->cfg = *cfg;
+    rx->dev = cfg->hip_device;
+    if (hipSetDevice(rx->dev) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", rx->dev);
+        return nullptr;
+    }
+    if (cfg->stream) {
+        rx->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+        if (hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error("hipStreamCreate failed");
+            return nullptr;
+        }
+        rx->own_stream = true;
+    }
+    for (auto &e : rx->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            set_error("hipEventCreate failed");
+            return nullptr;
+        }
+    }
+    rx->exact = (cfg->flags & OOKD_RX_EXACT_FIR) != 0;
+    rx->max_captures = cfg->max_captures ? cfg->max_captures : 1;
+    rx->max_samples = cfg->max_samples;
+
+    // ---- filter ---------------------------------------------------------------
+    std::vector<float> taps_dev;
+    if (filter) {
+        if (filter->stages.size() > (size_t)kMaxStages) {
+            set_error("filter has %zu stages, this build supports %d", filter->stages.size(), kMaxStages);
+            return nullptr;
+        }
+        rx->num_stages = (uint32_t)filter->stages.size();
+        rx->total_decim = filter->total_decimation;
+        uint64_t mult = 1;
+        for (uint32_t s = 0; s < rx->num_stages; ++s) {
+            const auto &st = filter->stages[s];
+            FirStageDev d{};
+            d.decim = st.decimation;
+            d.ntaps = (uint32_t)st.taps.size();
+            d.ntaps_pad = ((d.ntaps + kTapChunk - 1) / kTapChunk) * kTapChunk;
+            d.tap_off = (uint32_t)taps_dev.size();
+            taps_dev.insert(taps_dev.end(), st.taps.begin(), st.taps.end());
+            // zero padding keeps sums bit-identical: acc + (+-0) == acc
+            taps_dev.resize(d.tap_off + d.ntaps_pad, 0.0f);
+            rx->stage[s] = d;
+            rx->halo_needed += (uint64_t)(d.ntaps - 1) * mult;
+            mult *= d.decim;
+        }
+        rx->taps0 = filter->stages[0].taps;
+        if (rx->d_taps.alloc(taps_dev.size()) != OOKD_OK) return nullptr;
+        if (hipMemcpy(rx->d_taps.p, taps_dev.data(), taps_dev.size() * sizeof(float),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("tap upload failed");
+            return nullptr;
+        }
+    }
+    rx->p_star = power_threshold(cfg->threshold);
+    rx->p_lo = rx->p_hi = rx->p_star;
+    if (!rx->exact && rx->num_stages == 1 && rx->stage[0].decim == 1) {
+        guard_band(rx->taps0, rx->p_star, rx->p_lo, rx->p_hi);
+    }
+
+    // ---- state machine ------------------------------------------------------------
+    if (device) {
+        const size_t ns = device->state_duration_us.size();
+        const size_t nt = device->trig_cond.size();
+        if (ns > (size_t)kMaxStates || nt > (size_t)kMaxTriggers) {
+            set_error("device has %zu states / %zu triggers, this build supports %d / %d", ns, nt,
+                      kMaxStates, kMaxTriggers);
+            return nullptr;
+        }
+        std::unique_ptr<FsmTablesDev> t(new FsmTablesDev());
+        memset(t.get(), 0, sizeof(FsmTablesDev));
+        t->num_states = (uint32_t)ns;
+        t->max_bits = device->num_bits;
+        t->num_triggers = (uint32_t)nt;
+        for (size_t s = 0; s < ns; ++s) {
+            t->state_kmin[s] = device->state_kmin[s];
+            t->state_kmax[s] = device->state_kmax[s];
+            t->state_kto[s] = device->state_kto[s];
+            t->trig_begin[s] = device->trig_begin[s];
+        }
+        t->trig_begin[ns] = device->trig_begin[ns];
+        for (size_t i = 0; i < nt; ++i) {
+            t->trig_kmin[i] = device->trig_kmin[i];
+            t->trig_kmax[i] = device->trig_kmax[i];
+            t->trig_next[i] = device->trig_next[i];
+            t->trig_cond[i] = device->trig_cond[i];
+            t->trig_action[i] = device->trig_action[i];
+        }
+        if (rx->d_tables.alloc(1) != OOKD_OK) return nullptr;
+        if (hipMemcpy(rx->d_tables.p, t.get(), sizeof(FsmTablesDev), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("table upload failed");
+            return nullptr;
+        }
+        rx->have_fsm = true;
+        rx->num_bits = device->num_bits;
+    }
+
+    // ---- capacities -------------------------------------------------------------------
+    const uint64_t spb = cfg->samples_per_buffer;
+    if (cfg->segment_buffers) {
+        rx->seg_buffers = cfg->segment_buffers;
+    } else {
+        // ~2^19 decimated samples per segment
+        const uint64_t want = ((1ull << 19) * rx->total_decim + spb - 1) / spb;
+        rx->seg_buffers = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, 1u << 30));
+    }
+    rx->msg_slots = cfg->message_slots ? cfg->message_slots : 32;
+    rx->err_slots = 32;
+    uint32_t blocks = 0, segs = 0;
+    rx->geometry(rx->max_samples, true, rx->max_n_in, rx->max_n_out, rx->max_words, blocks, segs);
+    rx->max_blocks = blocks;
+    rx->max_segs_per_cap = std::max<uint32_t>(segs, 1);
+    const uint64_t total_out = rx->max_n_out * rx->max_captures;
+    rx->edge_capacity = cfg->edge_capacity ? cfg->edge_capacity : total_out / 16 + (1u << 20);
+    if (rx->edge_capacity > 0xfffffff0ull) rx->edge_capacity = 0xfffffff0ull;
+    rx->msg_capacity = std::max<uint64_t>(1u << 16, (uint64_t)rx->max_captures * 64);
+
+    const size_t caps = rx->max_captures;
+    const size_t nseg = caps * rx->max_segs_per_cap;
+    int rc = OOKD_OK;
+    rc |= rx->d_bits.alloc(caps * rx->max_words + 64);
+    if (cfg->flags & OOKD_RX_KEEP_FIR) rc |= rx->d_fir.alloc(2 * caps * rx->max_n_out + 2);
+    rc |= rx->d_halo.alloc(2 * (rx->halo_needed + 4));
+    rc |= rx->d_blk_count.alloc(caps * blocks + 1);
+    rc |= rx->d_blk_offset.alloc(caps * blocks + 1);
+    rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
+    rc |= rx->d_hdr.alloc(1);
+    if (rx->have_fsm) {
+        rc |= rx->d_state_in.alloc(nseg);
+        rc |= rx->d_state_out.alloc(2 * nseg);
+        rc |= rx->d_seg_msgs.alloc(nseg * rx->msg_slots);
+        rc |= rx->d_msgs.alloc(rx->msg_capacity);
+        rc |= rx->d_seg_msg_count.alloc(nseg);
+        rc |= rx->d_seg_err_count.alloc(nseg);
+        rc |= rx->d_seg_errs.alloc(nseg * rx->err_slots);
+    }
+    if (rc != OOKD_OK) return nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&rx->h_hdr), sizeof(ResultHeader)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&rx->h_msgs), rx->msg_capacity * sizeof(MsgDev)) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        return nullptr;
+    }
+    memset(rx->h_hdr, 0, sizeof(ResultHeader));
+    return rx.release();
+}
+
+void ookd_rx_destroy(ookd_rx *rx) { delete rx; }
+
+int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
+                           uint64_t samples_per_capture, uint64_t capture_stride_samples) {
+    clear_error();
+    if (!rx || (!d_iq && samples_per_capture)) {
+        set_error("ookd_rx_process_device: null argument");
+        return OOKD_ERR_ARG;
+    }
+    if (num_captures == 0 || num_captures > rx->max_captures || samples_per_capture > rx->max_samples) {
+        set_error("run of %u captures x %llu samples exceeds the context capacity (%u x %llu)",
+                  num_captures, (unsigned long long)samples_per_capture, rx->max_captures,
+                  (unsigned long long)rx->max_samples);
+        return OOKD_ERR_ARG;
+    }
+    if (num_captures > 1 && capture_stride_samples < samples_per_capture) {
+        set_error("capture stride smaller than the capture");
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    rx->run_caps = num_captures;
+    rx->run_n_valid = samples_per_capture;
+    rx->geometry(samples_per_capture, true, rx->run_n_in, rx->run_n_out, rx->run_words,
+                 rx->run_blocks, rx->run_segs_per_cap);
+    rx->stats = ookd_rx_stats{};
+    int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
+    if (rc != OOKD_OK) return rc;
+    rc = rx->fsm_to_fixpoint(nullptr, true, false);
+    if (rc != OOKD_OK) return rc;
+    return rx->fetch_results();
+}
+
+int ookd_rx_process_host(ookd_rx *rx, const int16_t *iq, uint64_t num_samples) {
+    clear_error();
+    if (!rx || (!iq && num_samples)) {
+        set_error("ookd_rx_process_host: null argument");
+        return OOKD_ERR_ARG;
+    }
+    if (num_samples > rx->max_samples) {
+        set_error("capture of %llu samples exceeds max_samples %llu", (unsigned long long)num_samples,
+                  (unsigned long long)rx->max_samples);
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    if (!rx->d_stage_in.p) {
+        int rc = rx->d_stage_in.alloc(2 * rx->max_samples + 8);
+        if (rc != OOKD_OK) return rc;
+    }
+    if (num_samples) {
+        HIPCHK(hipMemcpyAsync(rx->d_stage_in.p, iq, num_samples * 4, hipMemcpyHostToDevice, rx->stream));
+    }
+    return ookd_rx_process_device(rx, rx->d_stage_in.p, 1, num_samples, num_samples);
+}
+
+uint64_t ookd_rx_halo_samples(const ookd_rx *rx) { return rx ? rx->halo_needed : 0; }
+
+int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, const int16_t *halo,
+                        uint64_t halo_samples, int last_shard, const ookd_fsm_state *state_in,
+                        ookd_fsm_state *state_out) {
+    clear_error();
+    if (!rx || (!d_iq && num_samples) || num_samples > rx->max_samples) {
+        set_error("ookd_rx_shard_begin: bad argument");
+        return OOKD_ERR_ARG;
+    }
+    const uint64_t spb = rx->cfg.samples_per_buffer;
+    const uint64_t align = spb / gcd64(spb, rx->total_decim) * rx->total_decim;
+    if (!last_shard && (num_samples % align) != 0) {
+        set_error("shard of %llu samples is not a multiple of lcm(samples_per_buffer, decimation) = %llu",
+                  (unsigned long long)num_samples, (unsigned long long)align);
+        return OOKD_ERR_ARG;
+    }
+    if (halo && halo_samples < rx->halo_needed) {
+        set_error("halo of %llu samples is shorter than the %llu the filter needs",
+                  (unsigned long long)halo_samples, (unsigned long long)rx->halo_needed);
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    uint32_t hl = 0;
+    if (halo && rx->halo_needed) {
+        hl = (uint32_t)rx->halo_needed;
+        HIPCHK(hipMemcpyAsync(rx->d_halo.p, halo + 2 * (halo_samples - hl), (size_t)hl * 4,
+                              hipMemcpyHostToDevice, rx->stream));
+    }
+    rx->run_caps = 1;
+    rx->run_n_valid = num_samples;
+    rx->geometry(num_samples, last_shard != 0, rx->run_n_in, rx->run_n_out, rx->run_words,
+                 rx->run_blocks, rx->run_segs_per_cap);
+    rx->stats = ookd_rx_stats{};
+    int rc = rx->front_and_edges(d_iq, num_samples, hl ? rx->d_halo.p : nullptr, hl);
+    if (rc != OOKD_OK) return rc;
+    static_assert(sizeof(ookd_fsm_state) == sizeof(FsmStateDev), "fsm state layout");
+    rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), true, false);
+    if (rc != OOKD_OK) return rc;
+    rc = rx->fetch_results();
+    if (rc != OOKD_OK) return rc;
+    if (state_out && rx->have_fsm && rx->run_n_out > 0) {
+        const size_t nseg = rx->run_segs_per_cap;
+        HIPCHK(hipMemcpy(state_out, rx->d_state_out.p + (size_t)rx->final_parity * nseg + (nseg - 1),
+                         sizeof(FsmStateDev), hipMemcpyDeviceToHost));
+    } else if (state_out) {
+        if (state_in) *state_out = *state_in;
+        else memset(state_out, 0, sizeof(*state_out));
+    }
+    return OOKD_OK;
+}
+
+int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in, ookd_fsm_state *state_out) {
+    clear_error();
+    if (!rx || !state_in) {
+        set_error("ookd_rx_shard_refine: null argument");
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    if (!rx->have_fsm || rx->run_n_out == 0) {
+        if (state_out) *state_out = *state_in;
+        return OOKD_OK;
+    }
+    int rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), false, true);
+    if (rc != OOKD_OK) return rc;
+    rc = rx->fetch_results();
+    if (rc != OOKD_OK) return rc;
+    if (state_out) {
+        const size_t nseg = rx->run_segs_per_cap;
+        HIPCHK(hipMemcpy(state_out, rx->d_state_out.p + (size_t)rx->final_parity * nseg + (nseg - 1),
+                         sizeof(FsmStateDev), hipMemcpyDeviceToHost));
+    }
+    return OOKD_OK;
+}
+
+uint64_t ookd_rx_num_messages(const ookd_rx *rx) { return rx ? rx->num_msgs : 0; }
+
+const ookd_message *ookd_rx_messages(const ookd_rx *rx) {
+    static_assert(sizeof(ookd_message) == sizeof(MsgDev), "message layout");
+    return rx ? reinterpret_cast<const ookd_message *>(rx->h_msgs) : nullptr;
+}
+
+int ookd_rx_get_stats(const ookd_rx *rx, ookd_rx_stats *out) {
+    if (!rx || !out) return OOKD_ERR_ARG;
+    *out = rx->stats;
+    return OOKD_OK;
+}
+
+uint64_t ookd_rx_bit_words(const ookd_rx *rx) { return rx ? rx->run_words : 0; }
+
+int ookd_rx_get_bits(const ookd_rx *rx, uint32_t capture, uint64_t *words, uint64_t capacity_words) {
+    clear_error();
+    if (!rx || !words || capture >= rx->run_caps) return OOKD_ERR_ARG;
+    const uint64_t n = std::min<uint64_t>(capacity_words, rx->run_words);
+    HIPCHK(hipSetDevice(rx->dev));
+    HIPCHK(hipMemcpy(words, rx->d_bits.p + (size_t)capture * rx->run_words, n * 8, hipMemcpyDeviceToHost));
+    return OOKD_OK;
+}
+
+int ookd_rx_get_edges(const ookd_rx *rx, uint32_t capture, uint64_t *edges, uint64_t capacity,
+                      uint64_t *num_edges) {
+    clear_error();
+    if (!rx || capture >= rx->run_caps) return OOKD_ERR_ARG;
+    HIPCHK(hipSetDevice(rx->dev));
+    if (rx->run_n_out == 0) {
+        if (num_edges) *num_edges = 0;
+        return OOKD_OK;
+    }
+    uint32_t off[2];
+    HIPCHK(hipMemcpy(&off[0], rx->d_blk_offset.p + (size_t)capture * rx->run_blocks, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&off[1], rx->d_blk_offset.p + (size_t)(capture + 1) * rx->run_blocks, 4,
+                     hipMemcpyDeviceToHost));
+    const uint64_t n = off[1] - off[0];
+    if (num_edges) *num_edges = n;
+    if (edges && n) {
+        HIPCHK(hipMemcpy(edges, rx->d_edges.p + off[0], std::min<uint64_t>(n, capacity) * 8,
+                         hipMemcpyDeviceToHost));
+    }
+    return OOKD_OK;
+}
+
+int ookd_rx_get_fir(const ookd_rx *rx, uint32_t capture, ookd_complexf *out, uint64_t capacity) {
+    clear_error();
+    if (!rx || !out || capture >= rx->run_caps) return OOKD_ERR_ARG;
+    if (!rx->d_fir.p) {
+        set_error("ookd_rx_get_fir needs OOKD_RX_KEEP_FIR");
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    const uint64_t n = std::min<uint64_t>(capacity, rx->run_n_out);
+    HIPCHK(hipMemcpy(out, rx->d_fir.p + 2 * (size_t)capture * rx->run_n_out, n * 8, hipMemcpyDeviceToHost));
+    return OOKD_OK;
+}
+
+int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity, uint64_t *num) {
+    clear_error();
+    if (!rx) return OOKD_ERR_ARG;
+    if (num) *num = rx->stats.num_errors;
+    if (!rx->have_fsm || rx->run_n_out == 0 || !samples || capacity == 0) return OOKD_OK;
+    HIPCHK(hipSetDevice(rx->dev));
+    const size_t nseg = (size_t)rx->run_caps * rx->run_segs_per_cap;
+    std::vector<uint32_t> counts(nseg);
+    std::vector<uint64_t> errs(nseg * rx->err_slots);
+    HIPCHK(hipMemcpy(counts.data(), rx->d_seg_err_count.p, nseg * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(errs.data(), rx->d_seg_errs.p, errs.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t at = 0;
+    for (size_t s = 0; s < nseg && at < capacity; ++s) {
+        const uint32_t c = std::min<uint32_t>(counts[s], rx->err_slots);
+        for (uint32_t i = 0; i < c && at < capacity; ++i) samples[at++] = errs[s * rx->err_slots + i];
+    }
+    return OOKD_OK;
+}
+
+}  // extern "C"
