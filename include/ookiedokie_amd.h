@@ -163,6 +163,7 @@ typedef struct ookd_rx_config {
     uint64_t edge_capacity;         /* 0 = default (max_samples/16 + 1M)      */
     uint32_t segment_buffers;       /* buffers per FSM segment, 0 = default   */
     uint32_t message_slots;         /* per segment, 0 = default               */
+    uint64_t message_capacity;      /* messages per run, 0 = default (65536)  */
     void *stream;                   /* hipStream_t to launch on, NULL = own   */
 } ookd_rx_config;
 

@@ -75,7 +75,7 @@ class RxConfig(C.Structure):
         ("samples_per_buffer", C.c_uint32), ("max_samples", C.c_uint64),
         ("max_captures", C.c_uint32), ("edge_capacity", C.c_uint64),
         ("segment_buffers", C.c_uint32), ("message_slots", C.c_uint32),
-        ("stream", C.c_void_p),
+        ("message_capacity", C.c_uint64), ("stream", C.c_void_p),
     ]
 
 
@@ -378,7 +378,7 @@ class Receiver:
                  samples_per_buffer: int = DEFAULT_SAMPLES_PER_BUF, hip_device: int = 0,
                  max_captures: int = 1, exact_fir: bool = False, keep_fir: bool = False,
                  edge_capacity: int = 0, segment_buffers: int = 0, message_slots: int = 0,
-                 stream: int = 0):
+                 message_capacity: int = 0, stream: int = 0):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = (RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
@@ -389,6 +389,7 @@ class Receiver:
         cfg.edge_capacity = edge_capacity
         cfg.segment_buffers = segment_buffers
         cfg.message_slots = message_slots
+        cfg.message_capacity = message_capacity
         cfg.stream = stream
         self._filter, self._device = filt, device
         self.payload_bytes = device.payload_bytes if device else 0

@@ -545,7 +545,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     const uint64_t total_out = rx->max_n_out * rx->max_captures;
     rx->edge_capacity = cfg->edge_capacity ? cfg->edge_capacity : total_out / 16 + (1u << 20);
     if (rx->edge_capacity > 0xfffffff0ull) rx->edge_capacity = 0xfffffff0ull;
-    rx->msg_capacity = std::max<uint64_t>(1u << 16, (uint64_t)rx->max_captures * 64);
+    rx->msg_capacity = cfg->message_capacity
+                           ? cfg->message_capacity
+                           : std::max<uint64_t>(1u << 16, (uint64_t)rx->max_captures * 64);
 
     const size_t caps = rx->max_captures;
     const size_t nseg = caps * rx->max_segs_per_cap;

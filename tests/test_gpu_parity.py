@@ -1,0 +1,512 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the
+CPU oracle on the same inputs (bit-exact for bits / edges / messages /
+payloads / error positions; FIR floats bit-exact in EXACT mode and within
+1e-5 of full scale in the default fused mode -- tolerance stated below),
+against the committed golden vectors, and -- at BASELINE.json sizes --
+through size-independent properties."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import edges_of, golden_path, iq_from_rle, stream_from_runs
+
+pytestmark = pytest.mark.gpu
+
+RATE = 3000000
+# FIR float tolerance (BASELINE.json north_star: "within 1e-5 relative"),
+# made well-defined as SURVEY.md hard part 2 prescribes:
+#   |y - y_ref| <= 1e-5 * max(|y_ref|, sum|h| * max|x|)
+FIR_RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ok():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from ookiedokie_amd import build as okbuild
+    okbuild.build()
+    import ookiedokie_amd as okm
+    okm.lib()
+    return okm
+
+
+def _flt(ok, name):
+    return ok.Filter.load(golden_path("filters", name)) if name else None
+
+
+def _ofir(oracle, name):
+    return oracle.load_filter_json(golden_path("filters", name)) if name else None
+
+
+def _dev(ok, name, rate=RATE):
+    return ok.Device.load(golden_path("devices", name), rate)
+
+
+def _odev(oracle, name, rate=RATE):
+    return oracle.load_device_json(golden_path("devices", name), rate)[0]
+
+
+def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, check_fir=False,
+             segment_buffers=0, rate=RATE):
+    f = _flt(ok, filt)
+    of = _ofir(oracle, filt)
+    dec = of.total_decimation if of else 1
+    d = _dev(ok, devname, rate // dec)
+    od = _odev(oracle, devname, rate // dec)
+    n = iq.size // 2
+    rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
+                     exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers)
+    got = rx.rx(iq)
+    want = oracle.rx(iq, of, thr, od, spb, want_bits=True, want_fir=check_fir)
+    assert got.stats["decimated_samples"] == want.decimated
+    bits = rx.bits()
+    assert bits.size == want.bits.size
+    diff = np.nonzero(bits != want.bits)[0]
+    assert diff.size == 0, "first differing bit at %s" % diff[:5]
+    assert list(rx.edges()) == list(edges_of(want.bits))
+    assert list(got.msg_samples) == list(want.msg_samples)
+    assert (got.payloads == want.payloads).all()
+    errs, nerr = rx.errors()
+    assert nerr == len(want.err_samples)
+    if nerr <= 32:
+        assert list(errs) == list(want.err_samples)
+    if check_fir:
+        y = rx.fir_output()
+        if exact or of is None or of.num_stages != 1 or int(of.decimation[0]) != 1:
+            assert (y.view(np.uint32) == want.fir.view(np.uint32)).all(), "FIR floats not bit-identical"
+        else:
+            scale = float(np.abs(of.taps).sum()) * float(np.abs(iq).max()) / 2048.0
+            tol = FIR_RTOL * np.maximum(np.abs(want.fir), scale)
+            assert (np.abs(y - want.fir) <= tol).all()
+    rx.close()
+    return got, want
+
+
+def _g1(vectors, noise_seed=None):
+    g = vectors["G1"]
+    iq = iq_from_rle(g["i_rle"], g["num_samples"])
+    if noise_seed is not None:
+        rng = np.random.default_rng(noise_seed)
+        iq = (iq + rng.integers(-40, 41, size=iq.size)).astype(np.int16)
+    return g, iq
+
+
+# ----------------------------------------------------------------- golden ----
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_g1_golden(ok, oracle, vectors, exact):
+    g, iq = _g1(vectors)
+    got, want = _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", exact=exact, check_fir=True)
+    s = g["survey"]
+    assert list(got.msg_samples) == s["msg_samples"]
+    assert all(got.payload_bits(i, 36) == s["payload_bits"] for i in range(3))
+    assert got.stats["num_edges"] == s["num_edges"]
+
+
+@pytest.mark.parametrize("spb", [1000, 4096, 65536])
+def test_g1_other_buffer_sizes(ok, oracle, vectors, spb):
+    g, iq = _g1(vectors)
+    got, _ = _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", spb=spb)
+    assert list(got.msg_samples) == g["survey"]["msg_samples"]
+
+
+def test_g2_golden(ok, oracle, vectors):
+    g = vectors["G2"]
+    iq = iq_from_rle(g["i_rle"], g["num_samples"])
+    got, _ = _compare(ok, oracle, iq, "fs32_fs4", "unknown-remote1", check_fir=True)
+    assert list(got.msg_samples) == g["survey"]["msg_samples"]
+    assert all(got.payload_bits(i, 32) == g["survey"]["payload_bits"] for i in range(2))
+
+
+@pytest.mark.parametrize("spb", [1000, 4096, 8192, 65536])
+def test_g3_error_drops_rest_of_buffer(ok, oracle, vectors, spb):
+    g, iq = _g1(vectors)
+    a, b, v = vectors["G3"]["glitch"]
+    iq[2 * a:2 * b:2] = v
+    got, want = _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", spb=spb)
+    assert len(got.msg_samples) == vectors["G3"]["survey_num_msgs"][str(spb)]
+
+
+# ----------------------------------------------- other filters / no filter ----
+
+@pytest.mark.parametrize("filt", ["fs128_fs16_dec4", "unity16", "unity1", None])
+def test_other_filters_noisy(ok, oracle, vectors, filt):
+    g, iq = _g1(vectors, noise_seed=11)
+    _compare(ok, oracle, iq, filt, "p3l-nexa2012", check_fir=True)
+
+
+def test_dec4_with_buffer_not_multiple_of_decimation(ok, oracle, vectors):
+    g, iq = _g1(vectors, noise_seed=12)
+    for spb in (1001, 4098, 8191):
+        _compare(ok, oracle, iq[:2 * 600000], "fs128_fs16_dec4", "p3l-nexa2012", spb=spb)
+
+
+def test_255_tap_filter(ok, oracle, vectors, tmp_path):
+    # BASELINE config 3 shape: 255 real taps = hamming-windowed sinc, cutoff Fs/64
+    n = np.arange(255) - 127
+    h = np.sinc(n / 32.0) * np.hamming(255)
+    h = (h / h.sum()).astype(np.float64)
+    p = tmp_path / "sinc255.json"
+    p.write_text(json.dumps({"filter": {"stages": [{"decimation": 1, "taps": list(h)}]}}))
+    g = vectors["G2"]
+    iq = iq_from_rle(g["i_rle"], g["num_samples"])
+    rng = np.random.default_rng(2)
+    iq = (iq + rng.integers(-40, 41, size=iq.size)).astype(np.int16)
+    f = ok.Filter.load(str(p))
+    of = oracle.load_filter_json(str(p))
+    for exact in (False, True):
+        d = _dev(ok, "unknown-remote1")
+        od = _odev(oracle, "unknown-remote1")
+        rx = ok.Receiver(f, d, max_samples=iq.size // 2, exact_fir=exact, keep_fir=True)
+        got = rx.rx(iq)
+        want = oracle.rx(iq, of, 0.1, od, 8192, want_bits=True, want_fir=True)
+        assert (rx.bits() == want.bits).all()
+        assert list(got.msg_samples) == list(want.msg_samples) and len(want.msg_samples) == 2
+        assert (got.payloads == want.payloads).all()
+        y = rx.fir_output()
+        if exact:
+            assert (y.view(np.uint32) == want.fir.view(np.uint32)).all()
+        else:
+            scale = float(np.abs(of.taps).sum()) * float(np.abs(iq).max()) / 2048.0
+            assert (np.abs(y - want.fir) <= FIR_RTOL * np.maximum(np.abs(want.fir), scale)).all()
+
+
+# ------------------------------------------------------------- guard band ----
+
+def test_guard_band_forces_exact_recompute(ok, oracle):
+    """A signal whose filtered magnitude hovers around the threshold: the
+    fused path must hand every borderline sample to the exact recompute and
+    still produce the oracle's bits."""
+    rng = np.random.default_rng(9)
+    n = 400000
+    # DC gain of fs32_fs4 is ~1; amplitude ~0.1 FS = 205 LSB, tiny ramp + noise
+    base = 204.6 + 0.8 * np.sin(np.arange(n) / 5000.0)
+    i = np.round(base + rng.normal(0, 0.6, n)).astype(np.int16)
+    q = rng.integers(-2, 3, n).astype(np.int16)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2], iq[1::2] = i, q
+    f = _flt(ok, "fs32_fs4")
+    of = _ofir(oracle, "fs32_fs4")
+    rx = ok.Receiver(f, None, max_samples=n, edge_capacity=n + 1024)
+    got = rx.rx(iq)
+    want = oracle.rx(iq, of, 0.1, None, 8192, want_bits=True)
+    assert (rx.bits() == want.bits).all()
+    assert got.stats["guard_recomputes"] > 100
+    assert list(rx.edges()) == list(edges_of(want.bits))
+    assert 0.05 < want.bits.mean() < 0.95
+
+
+@pytest.mark.parametrize("thr", [0.0, -1.0, 1e-6, 0.5, 0.999, 16.0, 30.0, float("nan")])
+def test_threshold_edge_values(ok, oracle, vectors, thr):
+    g, iq = _g1(vectors, noise_seed=4)
+    iq = iq[:2 * 200000]
+    f = _flt(ok, "fs32_fs4")
+    of = _ofir(oracle, "fs32_fs4")
+    for exact in (False, True):
+        rx = ok.Receiver(f, None, max_samples=iq.size // 2, threshold=thr, exact_fir=exact,
+                         edge_capacity=iq.size)
+        rx.rx(iq)
+        want = oracle.rx(iq, of, thr, None, 8192, want_bits=True)
+        assert (rx.bits() == want.bits).all(), (thr, exact)
+
+
+# ---------------------------------------------------------- ragged / empty ----
+
+@pytest.mark.parametrize("n", [0, 1, 3, 31, 64, 4095, 4096, 4097, 8191, 8192, 8193, 20000])
+def test_ragged_lengths(ok, oracle, vectors, n):
+    g, iq = _g1(vectors, noise_seed=6)
+    iq = iq[2 * 11000:2 * (11000 + n)].copy()      # starts inside the idle gap before a pulse
+    for filt in ("fs32_fs4", "fs128_fs16_dec4", None):
+        _compare(ok, oracle, iq, filt, "p3l-nexa2012", spb=4096)
+
+
+# ---------------------------------------------------------- state machine ----
+
+def _iq_from_stream(stream, amp=1945):
+    iq = np.zeros(2 * stream.size, dtype=np.int16)
+    iq[0::2] = stream.astype(np.int16) * amp
+    return iq
+
+
+def test_g7_tolerance_boundaries(ok, oracle, vectors):
+    g = vectors["G7"]
+    from tests.golden import make_golden as mg
+    d = _dev(ok, g["device"])
+    for c in g["cases"]:
+        runs = mg.p3l_runs(g["payload_bits"], **{c["param"]: c["value"]})
+        iq = _iq_from_stream(stream_from_runs(runs))
+        rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=g["spb"])
+        got = rx.rx(iq)
+        assert list(got.msg_samples) == c["msg_samples"], c
+        rx.close()
+
+
+@pytest.mark.parametrize("segment_buffers", [1, 3, 0])
+def test_reference_fsm_fixtures_random_streams(ok, oracle, vectors, segment_buffers):
+    for case in vectors["random_streams"]:
+        d = _dev(ok, case["device"], case["rate"])
+        iq = _iq_from_stream(stream_from_runs(case["runs"]))
+        for buf, want in case["ref_fsm"].items():
+            rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=int(buf),
+                             segment_buffers=segment_buffers)
+            got = rx.rx(iq)
+            # the file backend pads the capture to whole buffers; the fixtures
+            # were cut at the end of the stream: ignore anything in the padding
+            keep = got.msg_samples < len(iq) // 2
+            assert list(got.msg_samples[keep]) == want["msg_samples"], (case["device"], buf)
+            assert [bytes(p).hex() for p in got.payloads[keep]] == want["payloads"]
+            rx.close()
+
+
+def test_random_devices_match_oracle(ok, oracle):
+    from tests.test_oracle import _random_fsm
+    rng = np.random.default_rng(123)
+    for it in range(40):
+        rate = int(rng.choice([3000000, 1000000, 750000, 48000]))
+        od = _random_fsm(oracle, rng, rate)
+        d = ok.Device.from_tables(
+            max_bits=od.max_bits, sample_rate=rate, state_duration_us=od.state_duration_us,
+            state_timeout_us=od.state_timeout_us, trig_begin=od.trig_begin, trig_cond=od.trig_cond,
+            trig_action=od.trig_action, trig_next=od.trig_next, trig_duration_us=od.trig_duration_us)
+        scale = rate / 1e6
+        runs = [max(1, int(rng.choice([30, 60, 100, 200, 250, 400, 1000, 5000]) * scale
+                       * rng.uniform(0.8, 1.2))) for _ in range(int(rng.integers(20, 300)))]
+        stream = stream_from_runs(runs)
+        iq = _iq_from_stream(stream)
+        for spb, segb in ((97, 1), (512, 2), (4096, 3)):
+            # a random device may emit a message on every sample: one slot per sample
+            rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=spb,
+                             segment_buffers=segb, message_slots=spb * segb + 1,
+                             message_capacity=1 << 20, edge_capacity=iq.size)
+            got = rx.rx(iq)
+            want = oracle.rx(iq, None, 0.1, od, spb, msg_cap=1 << 20)
+            assert list(got.msg_samples) == list(want.msg_samples), (it, spb)
+            assert (got.payloads == want.payloads).all(), (it, spb)
+            assert got.stats["num_errors"] == len(want.err_samples), (it, spb)
+            rx.close()
+
+
+# ------------------------------------------------------- batched / sharded ----
+
+def test_batched_captures_are_independent(ok, oracle, vectors):
+    import torch
+    g, iq = _g1(vectors)
+    n = 300000
+    caps = []
+    for c in range(5):
+        rng = np.random.default_rng(100 + c)
+        off = int(rng.integers(0, 600000))
+        x = iq[2 * off:2 * (off + n)].copy()
+        x = (x + rng.integers(-40, 41, size=x.size)).astype(np.int16)
+        caps.append(x)
+    stride = n + 12          # padded stride, multiple of 4 samples
+    host = np.zeros((5, 2 * stride), dtype=np.int16)
+    for c in range(5):
+        host[c, :2 * n] = caps[c]
+    dev_t = torch.from_numpy(host).cuda()
+    f = _flt(ok, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012")
+    rx = ok.Receiver(f, d, max_samples=n, max_captures=5)
+    got = rx.rx_device(dev_t.data_ptr(), n, num_captures=5, stride=stride)
+    of = _ofir(oracle, "fs32_fs4")
+    od = _odev(oracle, "p3l-nexa2012")
+    total = 0
+    for c in range(5):
+        want = oracle.rx(caps[c], of, 0.1, od, 8192, want_bits=True)
+        assert (rx.bits(c) == want.bits).all(), c
+        gc = got.for_capture(c)
+        assert list(gc.msg_samples) == list(want.msg_samples)
+        assert (gc.payloads == want.payloads).all()
+        total += len(want.msg_samples)
+    assert total == len(got.msg_samples)
+
+
+@pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
+def test_sharded_capture_equals_whole(ok, oracle, vectors, filt):
+    """One capture cut into shards (as 8 GPUs would hold it): halo + carried
+    FSM state reproduce the single-pass result."""
+    import torch
+    g, iq = _g1(vectors, noise_seed=21)
+    of = _ofir(oracle, filt)
+    dec = of.total_decimation
+    f = _flt(ok, filt)
+    d = _dev(ok, "p3l-nexa2012", RATE // dec)
+    od = _odev(oracle, "p3l-nexa2012", RATE // dec)
+    spb = 8192
+    n = iq.size // 2
+    want = oracle.rx(iq, of, 0.1, od, spb, want_bits=True)
+    shard = 40 * spb
+    bounds = list(range(0, n, shard)) + [n]
+    nsh = len(bounds) - 1
+    rxs, outs, bits = [], [None] * nsh, [None] * nsh
+    dev_t = torch.from_numpy(iq.copy()).cuda()
+    ins = [None] * nsh
+    H = None
+    for r in range(nsh):
+        rx = ok.Receiver(f, d, max_samples=shard, samples_per_buffer=spb)
+        H = rx.halo_samples
+        lo, hi = bounds[r], bounds[r + 1]
+        halo = iq[2 * (lo - H):2 * lo] if r > 0 and H else None
+        _, out = rx.shard_begin(dev_t.data_ptr() + 4 * lo, hi - lo, halo, r == nsh - 1, None)
+        rxs.append(rx)
+        outs[r] = out
+    # propagate the carried state until nothing changes (what ranks do over RCCL)
+    for _round in range(nsh + 1):
+        changed = False
+        for r in range(1, nsh):
+            if ins[r] is None or ins[r].key() != outs[r - 1].key():
+                ins[r] = outs[r - 1]
+                _, o = rxs[r].shard_refine(ins[r])
+                if o.key() != outs[r].key():
+                    changed = True
+                outs[r] = o
+        if not changed:
+            break
+    msgs, pays = [], []
+    off = 0
+    for r in range(nsh):
+        res = rxs[r]._result()
+        msgs += [int(s) + off for s in res.msg_samples]
+        pays += [bytes(p) for p in res.payloads]
+        b = rxs[r].bits()
+        assert (b == want.bits[off:off + b.size]).all(), r
+        off += b.size
+    assert off == want.decimated
+    assert msgs == list(want.msg_samples)
+    assert pays == [bytes(p) for p in want.payloads]
+
+
+# ------------------------------------------------------- fine-grained APIs ----
+
+@pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4", "unity16"])
+@pytest.mark.parametrize("chunk", [7, 33, 1000, 8192])
+def test_stream_fir_matches_oracle_for_any_chunking(ok, oracle, vectors, filt, chunk):
+    g, iq = _g1(vectors, noise_seed=31)
+    x = oracle.unpack(iq[:2 * 30000])
+    sf = ok.StreamFir(_flt(ok, filt), 8192)
+    outs = [sf.filter_and_decimate(x[o:o + chunk]) for o in range(0, x.shape[0], chunk)]
+    y = np.concatenate(outs)
+    want = oracle.fir_run(_ofir(oracle, filt), x, chunk)
+    assert y.shape == want.shape
+    assert (y.view(np.uint32) == want.view(np.uint32)).all()
+    sf.reset()
+    y2 = sf.filter_and_decimate(x[:100])
+    assert (y2.view(np.uint32) == want[:y2.shape[0]].view(np.uint32)).all()
+
+
+def test_fir_impulse_known_answers(ok, oracle):
+    x = np.zeros((100, 2), np.float32)
+    x[49, 0] = 1.0
+    f = _flt(ok, "fs32_fs4")
+    y = ok.StreamFir(f, 4096).filter_and_decimate(x)
+    _, taps = f.stage(0)
+    assert (y[49:81, 0].view(np.uint32) == taps.view(np.uint32)).all() and not y[:, 1].any()
+    y = ok.StreamFir(_flt(ok, "unity16"), 4096).filter_and_decimate(x)
+    assert list(np.nonzero(y[:, 0])[0]) == list(range(49, 65))
+
+
+def test_backend_rx_matches_file_backend_semantics(ok, oracle, vectors, tmp_path):
+    g, iq = _g1(vectors, noise_seed=41)
+    iq = iq[:2 * 20000].copy()
+    path = tmp_path / "cap.sc16q11"
+    iq.tofile(path)
+    be = ok.HipFileBackend(str(path), samples_per_buffer=8192)
+    chunks, status = [], 0
+    while status == 0:
+        status, x = be.rx(8192)
+        if status == 0:
+            chunks.append(x)
+    assert status == ok.FILE_EOF
+    y = np.concatenate(chunks)
+    assert y.shape[0] == 3 * 8192                   # short final read zero padded
+    want = oracle.unpack(iq)
+    assert (y[:20000].view(np.uint32) == want.view(np.uint32)).all()
+    assert not y[20000:].any()
+    ptr, n = be.capture()
+    assert n == 20000 and ptr
+    f = _flt(ok, "fs32_fs4")
+    rx = ok.Receiver(f, None, max_samples=n)
+    rx.rx_device(ptr, n)
+    assert (rx.bits() == oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, None, 8192,
+                                   want_bits=True).bits).all()
+
+
+def test_synth_device_fill_equals_host_fill(ok):
+    import torch
+    d = _dev(ok, "p3l-nexa2012")
+    n = 3_000_001
+    syn = ok.Synth(d, n, seed=77)
+    t = torch.empty(2 * n, dtype=torch.int16, device="cuda")
+    syn.fill_device(t.data_ptr())
+    torch.cuda.synchronize()
+    assert (t.cpu().numpy() == syn.fill_host()).all()
+    t2 = torch.empty(2 * 1000, dtype=torch.int16, device="cuda")
+    syn.fill_device(t2.data_ptr(), first=1234567, count=1000)
+    torch.cuda.synchronize()
+    assert (t2.cpu().numpy() == syn.fill_host(1234567, 1000)).all()
+
+
+# ------------------------------------------------------------ bench shape ----
+
+def test_synthetic_capture_matches_oracle_16M(ok, oracle):
+    """BASELINE config-2 recipe at a size the oracle finishes in seconds."""
+    import torch
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    n = 1 << 24
+    syn = ok.Synth(d, n, seed=0x00C0FFEE + 2)
+    t = torch.empty(2 * n, dtype=torch.int16, device="cuda")
+    syn.fill_device(t.data_ptr())
+    torch.cuda.synchronize()
+    f = _flt(ok, "fs32_fs4")
+    rx = ok.Receiver(f, d, max_samples=n)
+    got = rx.rx_device(t.data_ptr(), n)
+    iq = t.cpu().numpy()
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, od, 8192, want_bits=True)
+    assert (rx.bits() == want.bits).all()
+    assert list(got.msg_samples) == list(want.msg_samples)
+    assert (got.payloads == want.payloads).all()
+    assert got.stats["num_errors"] == len(want.err_samples)
+    # decoded payloads are a subsequence of what was transmitted
+    sent = [syn.message(i)[1] for i in range(syn.num_messages)]
+    it = iter(sent)
+    assert all(any(bytes(p) == s for s in it) for p in got.payloads)
+    assert len(got.msg_samples) >= 0.8 * (syn.num_messages - 2)
+
+
+def test_full_size_properties_1GiB(ok):
+    """BASELINE config 2 at full size (268 435 456 samples): properties that
+    do not need the oracle -- every decoded payload was transmitted, in
+    order; OUTPUT_READY follows each decoded message's start by the known
+    waveform length; the decode is idempotent; the edge list is sorted."""
+    import torch
+    d = _dev(ok, "p3l-nexa2012")
+    n = 1 << 28
+    syn = ok.Synth(d, n, seed=0x00C0FFEE + 2)
+    t = torch.empty(2 * n + 2 * 8192, dtype=torch.int16, device="cuda")
+    syn.fill_device(t.data_ptr())
+    torch.cuda.synchronize()
+    f = _flt(ok, "fs32_fs4")
+    rx = ok.Receiver(f, d, max_samples=n)
+    got = rx.rx_device(t.data_ptr(), n)
+    again = rx.rx_device(t.data_ptr(), n)
+    assert list(got.msg_samples) == list(again.msg_samples)
+    assert (got.payloads == again.payloads).all()
+    starts = np.array([syn.message(i)[0] for i in range(syn.num_messages)])
+    sent = [syn.message(i)[1] for i in range(syn.num_messages)]
+    assert len(got.msg_samples) >= 0.8 * (len(sent) - 2)
+    j = 0
+    for s, p in zip(got.msg_samples, got.payloads):
+        while j < len(sent) and sent[j] != bytes(p):
+            j += 1
+        assert j < len(sent), "decoded a payload that was never sent"
+        # OUTPUT_READY lands inside the transmitted waveform of that message
+        assert starts[j] < int(s) < starts[j] + 500000
+        j += 1
+    # edge list is sorted and consistent with the bit stream's popcount of changes
+    e = rx.edges()
+    assert (np.diff(e.astype(np.int64)) > 0).all()
+    assert got.stats["num_edges"] == e.size
