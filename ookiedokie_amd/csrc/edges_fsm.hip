@@ -1,0 +1,793 @@
+// edges_fsm.hip -- level-change extraction and the symbol state machine.
+//
+//   edges : packed bit words -> sorted list of level changes
+//           (the content of --rx-rec-dig, src/ookiedokie.c:146-169)
+//   fsm   : the table-driven symbol state machine run over that list,
+//           many segments of a capture in parallel, with a fix-point on the
+//           state carried from one segment to the next
+//           (reference, per sample: src/state_machine.c:421-556; the
+//            drop-rest-of-buffer rule: src/device.c:634-658)
+//
+// Why edges: between two level changes only `always` / `timeout` /
+// `msg_complete` triggers can fire, each at a sample count known from the
+// tables, so a run of constant level is advanced in O(1) instead of sample
+// by sample; the result is identical to feeding every sample
+// (SURVEY.md section 7 step 6).
+#include "kernels.hpp"
+
+namespace ookd {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+    return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) {
+    return ((uint64_t)rl((uint32_t)(v >> 32), lane) << 32) | rl((uint32_t)v, lane);
+}
+
+// ---------------------------------------------------------------------------
+// edges: count per 4096-bit block, two-level exclusive scan, compact
+// ---------------------------------------------------------------------------
+
+// word of level changes: bit b set <=> sample 64*w+b differs from its
+// predecessor (the sample before a capture counts as 0, as record_dig's
+// first line does for sample 0, ookiedokie.c:150-153).
+__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w) {
+    const uint64_t cur = words[w];
+    const uint64_t prev_top = (w == 0) ? 0ull : (words[w - 1] >> 63);
+    return cur ^ ((cur << 1) | prev_top);
+}
+
+__global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
+    if (wave >= total_blocks) return;
+    const uint32_t cap = wave / p.blocks_per_cap;
+    const uint32_t blk = wave % p.blocks_per_cap;
+    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id());
+    uint32_t c = (uint32_t)__popcll(e);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane_id() == 0) p.blk_count[wave] = c;
+}
+
+// level 1: each workgroup scans kScanGroup consecutive block counts
+// (coalesced 16 B per lane), writes group-local exclusive prefixes and the
+// group total.
+__global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t n = p.num_captures * p.blocks_per_cap;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * kScanGroup + tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? p.blk_count[base + i] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if ((int)lane_id() >= d) inc += t;
+    }
+    if (lane_id() == 63) wave_sum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) before += wave_sum[w];
+    uint32_t run = before + inc - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) p.blk_offset[base + i] = run;
+        run += v[i];
+    }
+    if (tid == 255) p.group_total[blockIdx.x] = run;
+}
+
+// level 2: one workgroup scans the group totals in place (exclusive) and
+// publishes the grand total in blk_offset[n].
+__global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams p) {
+    __shared__ uint32_t part[1024];
+    const uint32_t n = p.num_captures * p.blocks_per_cap;
+    const uint32_t ng = (n + kScanGroup - 1) / kScanGroup;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (ng + 1023u) / 1024u;
+    const uint32_t lo = min(tid * chunk, ng);
+    const uint32_t hi = min(lo + chunk, ng);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += p.group_total[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (tid >= d) ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t t = p.group_total[i];
+        p.group_total[i] = run;
+        run += t;
+    }
+    if (tid == 1023) {
+        p.blk_offset[n] = part[1023];
+        if ((uint64_t)part[1023] > p.edge_capacity) *p.overflow = 1;
+    }
+}
+
+// level 3 fused with the compaction: add the group base, keep the global
+// prefix for later readers, write the positions.
+__global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
+    if (wave >= total_blocks) return;
+    const uint32_t off = p.blk_offset[wave] + p.group_total[wave / kScanGroup];
+    if (lane_id() == 0) p.blk_offset[wave] = off;
+    if (p.blk_count[wave] == 0) return;
+    const uint32_t cap = wave / p.blocks_per_cap;
+    const uint32_t blk = wave % p.blocks_per_cap;
+    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+    const uint64_t w = (uint64_t)blk * kBlockWords + lane_id();
+    uint64_t e = change_word(words, w);
+    const uint32_t c = (uint32_t)__popcll(e);
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(inc, d);
+        if ((int)lane_id() >= d) inc += v;
+    }
+    uint64_t at = (uint64_t)off + (inc - c);
+    while (e) {
+        const int b = __ffsll((long long)e) - 1;
+        if (at < p.edge_capacity) p.edges[at] = w * 64 + (uint64_t)b;
+        ++at;
+        e &= e - 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// symbol state machine
+// ---------------------------------------------------------------------------
+//
+// Integer restatement of handle_rx_triggers / process (state_machine.c:
+// 421-539).  `k` = number of elapsed_us increments since it was last zeroed;
+// the host turned every duration window / timeout into a range of k by
+// replaying the reference's double accumulation, so the comparisons below
+// ARE the reference's float comparisons.  Counters are 32 bit and saturate
+// at kSat; the host refuses devices with a finite bound above 2^31, so a
+// saturated counter is "beyond every bound" exactly like the real one.
+//
+// Execution model: one wave per segment, control flow and state machine
+// state wave-uniform (SGPRs); the tables live in VGPRs, lane i holding
+// trigger i and state i, so "first trigger in file order that matches" is a
+// ballot + find-first-set and a table row is a v_readlane.
+
+enum { kCondAlways = 1, kCondPulseStart, kCondPulseEnd, kCondTimeout, kCondMsgComplete };
+enum { kActNone = 1, kActAppend0, kActAppend1, kActOutput };
+enum { kResError = -1, kResNone = 0, kResOutput = 1 };
+
+constexpr uint32_t kNone = 0xffffffffu;     // "no bound"
+constexpr uint32_t kSat = 0xfffffffeu;      // counters saturate here (< kNone)
+
+struct LaneTables {             // per-lane copies
+    uint32_t tkmin, tkmax, tinfo;       // trigger `lane`: cond | action << 8 | next << 16
+    uint32_t skmin, skmax, skto, srow;  // state `lane`: tbeg | tend << 8 | flags << 16
+    uint32_t max_bits;                  // wave-uniform
+};
+
+struct Fsm {                    // wave-uniform
+    uint32_t cur, nbits, prev, k;
+    uint64_t d0, d1, d2, d3, d4;
+};
+
+__device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
+    const uint64_t s = (uint64_t)k + m;
+    return s > kSat ? kSat : (uint32_t)s;
+}
+
+// Branch-free so the payload words stay in scalar registers (an address-taken
+// or dynamically indexed payload ends up in scratch memory).
+__device__ __forceinline__ uint64_t put_bit(uint64_t d, bool here, uint64_t m, bool one) {
+    const uint64_t v = one ? (d | m) : (d & ~m);
+    return here ? v : d;
+}
+
+__device__ __forceinline__ void set_bit(Fsm &f, uint32_t idx, bool one) {
+    const uint32_t wi = idx >> 6;
+    const uint64_t m = 1ull << (idx & 63u);
+    f.d0 = put_bit(f.d0, wi == 0, m, one);
+    f.d1 = put_bit(f.d1, wi == 1, m, one);
+    f.d2 = put_bit(f.d2, wi == 2, m, one);
+    f.d3 = put_bit(f.d3, wi == 3, m, one);
+    f.d4 = put_bit(f.d4, wi == 4, m, one);
+}
+
+// k has no influence in states flagged so; pin it to 0 there so that two
+// trajectories that differ only in how long they idled compare equal.
+__device__ __forceinline__ void canon(const LaneTables &t, Fsm &f) {
+    if (rl(t.srow, f.cur) & 0x10000u) f.k = 0;
+}
+
+// What happens once trigger `fired` of state s has matched with counter k
+// (state_machine.c:483-511).
+__device__ __forceinline__ int fsm_fire(const LaneTables &t, Fsm &f, uint32_t s, uint32_t fired) {
+    const uint32_t info = rl(t.tinfo, fired);
+    const uint32_t fc = info & 0xffu, act = (info >> 8) & 0xffu, next = info >> 16;
+    int result = kResNone;
+    bool ok = true;
+    if (fc == kCondPulseStart || fc == kCondPulseEnd) {     // :100-117
+        ok = f.k >= rl(t.skmin, s) && f.k <= rl(t.skmax, s);
+    }
+    if (ok) {
+        if (act == kActAppend0 || act == kActAppend1) {
+            // :365-385 stores while num_bits <= max_bits, always counts
+            if (f.nbits <= t.max_bits) set_bit(f, f.nbits, act == kActAppend1);
+            f.nbits += 1;
+        } else if (act == kActOutput) {
+            result = kResOutput;
+        }
+        f.cur = next;
+    } else {
+        result = kResError;
+        f.cur = 0;                                          // :505-509
+    }
+    f.k = 0;                                                // :511
+    return result;
+}
+
+// Per-lane: does my trigger match on a sample with counter k, previous level
+// prev and level b?  (state_machine.c:430-481)
+__device__ __forceinline__ bool trig_match(const LaneTables &t, uint32_t row, uint32_t kto, uint32_t k,
+                                           uint32_t prev, uint32_t b, uint32_t nbits) {
+    const uint32_t lane = lane_id();
+    const uint32_t cond = t.tinfo & 0xffu;
+    const bool in_row = lane >= (row & 0xffu) && lane < ((row >> 8) & 0xffu);
+    bool c = cond == kCondAlways;
+    c = c || (cond == kCondPulseStart && !prev && b);
+    c = c || (cond == kCondPulseEnd && prev && !b);
+    c = c || (cond == kCondTimeout && k >= kto);            // kto = kNone when no timeout
+    c = c || (cond == kCondMsgComplete && nbits >= t.max_bits);
+    return in_row && k >= t.tkmin && k <= t.tkmax && c;     // :119-133
+}
+
+// state_machine.c:421-519: one evaluation of the current state's triggers.
+__device__ __forceinline__ int fsm_eval(const LaneTables &t, Fsm &f, uint32_t b) {
+    const uint32_t s = f.cur;
+    const uint32_t row = rl(t.srow, s), kto = rl(t.skto, s);
+    const uint64_t ball = __ballot(trig_match(t, row, kto, f.k, f.prev, b, f.nbits));
+    if (ball == 0) {
+        f.k = sat_add(f.k, 1);                              // :513-515
+        return kResNone;
+    }
+    return fsm_fire(t, f, s, (uint32_t)__builtin_ctzll(ball));     // first in file order
+}
+
+// state_machine.c:521-539: reset clears the payload and is evaluated, then
+// the (possibly new) state is evaluated on the same sample.
+__device__ __forceinline__ int fsm_step(const LaneTables &t, Fsm &f, uint32_t b) {
+    if (f.cur == 0) {
+        f.nbits = 0;
+        f.d0 = f.d1 = f.d2 = f.d3 = f.d4 = 0;   // memset(data, 0, (max_bits+7)/8)
+        const int r = fsm_eval(t, f, b);
+        if (r != kResNone) return r;
+    }
+    return fsm_eval(t, f, b);
+}
+
+// Per-lane: with the input level constant (pulse triggers cannot fire), how
+// many evaluations from now (at k, k+1, ...) until my trigger fires?
+// kNone = never.
+__device__ __forceinline__ uint32_t trig_wait(const LaneTables &t, uint32_t row, uint32_t kto, uint32_t k,
+                                              uint32_t nbits) {
+    const uint32_t lane = lane_id();
+    const uint32_t cond = t.tinfo & 0xffu;
+    bool can = lane >= (row & 0xffu) && lane < ((row >> 8) & 0xffu);
+    uint32_t lo = t.tkmin;
+    if (cond == kCondTimeout) {
+        can = can && kto != kNone;
+        lo = lo > kto ? lo : kto;
+    } else if (cond == kCondMsgComplete) {
+        can = can && nbits >= t.max_bits;
+    } else {
+        can = can && cond == kCondAlways;
+    }
+    const uint32_t first = k > lo ? k : lo;
+    can = can && first <= t.tkmax && first <= kSat;
+    return can ? first - k : kNone;
+}
+
+// wave minimum of a per-lane u32
+__device__ __forceinline__ uint32_t wave_min(uint32_t w) {
+#define OOKD_ROW_MIN(SH)                                                                              \
+    {                                                                                                 \
+        const uint32_t o =                                                                            \
+            (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)w, 0x110 + (SH), 0xf, 0xf, false); \
+        w = o < w ? o : w;                                                                            \
+    }
+    OOKD_ROW_MIN(1)
+    OOKD_ROW_MIN(2)
+    OOKD_ROW_MIN(4)
+    OOKD_ROW_MIN(8)
+#undef OOKD_ROW_MIN
+    const uint32_t a = rl(w, 15), b = rl(w, 31), c = rl(w, 47), d = rl(w, 63);
+    const uint32_t m1 = a < b ? a : b, m2 = c < d ? c : d;
+    return m1 < m2 ? m1 : m2;
+}
+
+__device__ __forceinline__ uint64_t payload_word(uint64_t v, uint32_t i, uint32_t nbytes) {
+    if (8 * i >= nbytes) return 0;
+    if (8 * (i + 1) > nbytes) return v & ((1ull << ((nbytes - 8 * i) * 8)) - 1ull);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t clamp32(uint64_t v) {
+    return v == ~0ull ? kNone : (uint32_t)v;    // host guarantees finite bounds < 2^31
+}
+
+__device__ __forceinline__ LaneTables load_tables(const FsmTablesDev *g) {
+    LaneTables t;
+    const uint32_t l = lane_id();
+    t.tkmin = clamp32(g->trig_kmin[l]);
+    t.tkmax = clamp32(g->trig_kmax[l]);
+    t.tinfo = g->trig_info[l];
+    t.skmin = clamp32(g->state_kmin[l]);
+    t.skmax = clamp32(g->state_kmax[l]);
+    t.skto = clamp32(g->state_kto[l]);
+    t.srow = (g->state_tbeg[l] & 0xffu) | ((g->state_tend[l] & 0xffu) << 8) | ((g->state_flags[l] & 1u) << 16);
+    t.max_bits = rfl(g->max_bits);
+    return t;
+}
+
+// First decimated index of input buffer `buf`: floor(buf * spb / D)
+// (decimated sample j comes from input D*(j+1)-1).
+__device__ __forceinline__ uint64_t buffer_start(uint64_t buf, uint32_t spb, uint32_t D) {
+    return (buf * (uint64_t)spb) / D;       // buf*spb ~ input samples, fits 64 bits
+}
+
+__device__ __forceinline__ uint32_t bit_at(const uint64_t *words, uint64_t i) {
+    return (uint32_t)((words[i >> 6] >> (i & 63)) & 1ull);
+}
+
+// ---- segment boundaries -------------------------------------------------------
+//
+// A capture is cut every ~seg_len samples, but each cut is moved (within
+// +-seg_len/2) to the rising edge that ends the longest low-level gap in
+// that window: after a long gap the true state machine has almost certainly
+// timed out into its quiet state, which is what a segment assumes about its
+// incoming state.  The choice only affects how many fix-point rounds are
+// needed, never the result.
+__global__ __launch_bounds__(64) void fsm_cuts_kernel(const FsmParams p) {
+    const uint32_t id = blockIdx.x;                 // capture * (segs+1) + boundary
+    const uint32_t per = p.segs_per_cap + 1;
+    const uint32_t cap = id / per, bi = id % per;
+    uint64_t *bounds = p.seg_bounds + (size_t)cap * per;
+    const uint32_t lane = lane_id();
+    if (bi == 0 || bi == p.segs_per_cap) {
+        if (lane == 0) bounds[bi] = bi == 0 ? 0 : p.n_out;
+        return;
+    }
+    const uint64_t nominal = (uint64_t)bi * p.seg_len;
+    const uint64_t half = p.seg_len / 2;
+    const uint64_t w0 = nominal - half, w1 = min(nominal + half, p.n_out);
+    const uint32_t blk0 = cap * p.blocks_per_cap;
+    const uint64_t cap_e0 = p.blk_offset[blk0];
+    const uint64_t ne = (uint64_t)p.blk_offset[blk0 + p.blocks_per_cap] - cap_e0;
+    const uint64_t *edges = p.edges + cap_e0;
+    const uint64_t b0 = min(w0 >> 12, (uint64_t)p.blocks_per_cap - 1);
+    const uint64_t b1 = min((w1 >> 12) + 1, (uint64_t)p.blocks_per_cap);
+    const uint64_t i0 = (uint64_t)p.blk_offset[blk0 + b0] - cap_e0;
+    const uint64_t i1 = (uint64_t)p.blk_offset[blk0 + b1] - cap_e0;
+    uint64_t best_gap = 0, best_cut = 0;
+    for (uint64_t i = i0 + lane; i + 1 < ne && i < i1; i += 64) {
+        // level after edge i is (i+1)&1: low after odd-indexed edges
+        if ((i & 1ull) == 0) continue;
+        const uint64_t a = edges[i], b = edges[i + 1];
+        if (a < w0 || b >= w1) continue;
+        if (b - a > best_gap) {
+            best_gap = b - a;
+            best_cut = b;
+        }
+    }
+    // wave argmax (ties: smallest cut)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t og = __shfl_xor(best_gap, d), oc = __shfl_xor(best_cut, d);
+        if (og > best_gap || (og == best_gap && og != 0 && oc < best_cut)) {
+            best_gap = og;
+            best_cut = oc;
+        }
+    }
+    if (lane == 0) bounds[bi] = best_gap ? best_cut : min(nominal, p.n_out);
+}
+
+__global__ __launch_bounds__(64) void fsm_prepare_kernel(const FsmParams p, const FsmStateDev first,
+                                                         int have_first) {
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nseg = p.num_captures * p.segs_per_cap;
+    if (seg >= nseg) return;
+    const uint32_t cap = seg / p.segs_per_cap;
+    const uint32_t ls = seg % p.segs_per_cap;
+    SegState ss;
+    ss.st.cur = 0;
+    ss.st.nbits = 0;
+    ss.st.k = 0;
+    ss.st.prev = 0;
+    ss.st.pad = 0;
+    for (int i = 0; i < kPayloadWords; ++i) ss.st.data[i] = 0;
+    ss.skip_to = 0;
+    ss.pad = 0;
+    if (ls == 0) {
+        if (have_first) ss.st = first;
+    } else {
+        const uint64_t start = p.seg_bounds[(size_t)cap * (p.segs_per_cap + 1) + ls];
+        if (start > 0 && start <= p.n_out) {
+            ss.st.prev = bit_at(p.bits + (uint64_t)cap * p.words_per_cap, start - 1);
+        }
+        // assume the quiet state when the level before the segment is low
+        if (ss.st.prev == 0) ss.st.cur = p.tables->quiet_state;
+    }
+    p.state_in[seg] = ss;
+    p.seg_msg_count[seg] = 0;
+    p.seg_err_count[seg] = 0;
+}
+
+__device__ __forceinline__ bool seg_state_equal(const SegState &a, const SegState &b) {
+    bool eq = a.st.cur == b.st.cur && a.st.nbits == b.st.nbits && a.st.k == b.st.k &&
+              a.st.prev == b.st.prev && a.skip_to == b.skip_to;
+    for (int i = 0; i < kPayloadWords; ++i) eq = eq && a.st.data[i] == b.st.data[i];
+    return eq;
+}
+
+__global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32_t parity, uint32_t mode,
+                                                       uint32_t slot) {
+    const uint32_t seg = blockIdx.x;
+    const uint32_t nseg = p.num_captures * p.segs_per_cap;
+    const uint32_t cap = seg / p.segs_per_cap;
+    const uint32_t ls = seg % p.segs_per_cap;
+    const uint32_t lane = lane_id();
+    const uint32_t par = parity & 1u;
+    SegState *out_cur = p.state_out + (size_t)par * nseg;
+    const SegState *out_prev = p.state_out + (size_t)(par ^ 1u) * nseg;
+
+    // a finished fix-point makes the remaining rounds of a batch no-ops
+    if (mode == 1 && slot > 0 && p.changed[slot - 1] == 0) {
+        if (lane == 0) out_cur[seg] = out_prev[seg];
+        return;
+    }
+    if (mode != 0) {
+        bool rerun = false;
+        if (ls != 0) {
+            const SegState nin = out_prev[seg - 1];
+            rerun = !seg_state_equal(nin, p.state_in[seg]);
+            if (rerun && lane == 0) p.state_in[seg] = nin;
+        } else {
+            rerun = (mode == 2);
+        }
+        if (!rerun) {
+            if (lane == 0) out_cur[seg] = out_prev[seg];
+            return;
+        }
+        if (lane == 0) atomicAdd(&p.changed[slot], 1u);
+        __syncthreads();
+    } else if (lane == 0) {
+        atomicAdd(&p.changed[slot], 1u);            // a full round counts every segment
+    }
+
+    const LaneTables t = load_tables(p.tables);
+    const uint64_t *bounds = p.seg_bounds + (size_t)cap * (p.segs_per_cap + 1);
+    const uint64_t seg_start = rfl64(bounds[ls]);
+    const uint64_t seg_end = rfl64(bounds[ls + 1]);
+    const uint32_t seg_n = (uint32_t)(seg_end - seg_start);     // host keeps segments < 2^31 samples
+    const uint32_t blk0 = cap * p.blocks_per_cap;
+    const uint64_t cap_e0 = rfl(p.blk_offset[blk0]);
+    const uint64_t ne = (uint64_t)rfl(p.blk_offset[blk0 + p.blocks_per_cap]) - cap_e0;
+    const uint64_t *edges = p.edges + cap_e0;
+
+    const SegState sin = p.state_in[seg];
+    Fsm f;
+    f.cur = rfl(sin.st.cur);
+    f.nbits = rfl(sin.st.nbits);
+    f.prev = rfl(sin.st.prev);
+    {
+        const uint64_t k64 = rfl64(sin.st.k);
+        f.k = k64 > kSat ? kSat : (uint32_t)k64;
+    }
+    f.d0 = rfl64(sin.st.data[0]);
+    f.d1 = rfl64(sin.st.data[1]);
+    f.d2 = rfl64(sin.st.data[2]);
+    f.d3 = rfl64(sin.st.data[3]);
+    f.d4 = rfl64(sin.st.data[4]);
+    const uint64_t skip_to = rfl64(sin.skip_to);
+    uint64_t skip_out = 0;
+    // positions inside the segment are 32-bit offsets from seg_start
+    uint32_t pos = 0;
+    if (skip_to > seg_start) {
+        if (skip_to >= seg_end) {
+            pos = seg_n;                            // whole segment skipped
+            skip_out = skip_to;
+        } else {
+            pos = (uint32_t)(skip_to - seg_start);
+        }
+    }
+
+    // first edge at or after the start position (capture-local index): count
+    // the edges below it from the start of its 4096-sample block
+    uint64_t ci = 0;
+    if (pos < seg_n) {
+        const uint64_t apos = seg_start + pos;
+        const uint64_t blk = min(apos >> 12, (uint64_t)p.blocks_per_cap - 1);
+        uint64_t i = (uint64_t)rfl(p.blk_offset[blk0 + blk]) - cap_e0;
+        const uint64_t iend = (uint64_t)rfl(p.blk_offset[blk0 + blk + 1]) - cap_e0;
+        ci = i;
+        for (; i < iend; i += 64) {
+            const uint64_t idx = i + lane;
+            const bool lt = idx < iend && edges[idx] < apos;
+            ci += (uint64_t)__popcll(__ballot(lt));
+        }
+    }
+
+    MsgDev *msgs = p.seg_msgs + (size_t)seg * p.msg_slots;
+    uint64_t *errs = p.seg_errs + (size_t)seg * p.err_slots;
+    uint32_t nmsg = 0, nerr = 0, flags = 0;
+
+    // edge window: lane i holds the offset of edge wbase + i (kNone past the
+    // segment or the list); every in-segment edge offset is < seg_n
+    uint64_t wbase = ci;
+    uint32_t ev;
+#define OOKD_LOAD_WINDOW()                                                          \
+    {                                                                               \
+        const uint64_t idx_ = wbase + lane;                                         \
+        const uint64_t e_ = idx_ < ne ? edges[idx_] : ~0ull;                        \
+        ev = (e_ >= seg_end) ? kNone : (uint32_t)(e_ - seg_start);                  \
+    }
+    OOKD_LOAD_WINDOW()
+
+    uint32_t dbg_turns = 0, dbg_fused = 0, dbg_loads = 1;
+    const uint64_t dbg_t0 = p.debug ? __builtin_amdgcn_s_memtime() : 0;
+    while (pos < seg_n) {
+        dbg_turns++;
+        if (ci + 1 >= wbase + 64 || ci < wbase) {   // needs entries ci and ci+1
+            wbase = ci;
+            dbg_loads++;
+            OOKD_LOAD_WINDOW()
+        }
+        const uint32_t wi = (uint32_t)(ci - wbase);
+        const uint32_t e0 = rl(ev, wi);
+        const bool at_edge = (e0 == pos);
+        const uint32_t wia = wi + (at_edge ? 1u : 0u);
+        const uint64_t cia = ci + (at_edge ? 1 : 0);
+        const uint32_t b = (uint32_t)(cia & 1ull);  // level = parity of edges <= pos
+        int r;
+        uint32_t at;                                // offset of the sample that produced r
+        if (b == f.prev) {
+            // ---- constant level up to the next edge (or the segment end) ----------
+            const uint32_t e1 = rl(ev, wia);
+            const uint32_t run_end = e1 < seg_n ? e1 : seg_n;
+            const uint32_t n = run_end - pos;       // >= 1 samples with level b
+            const uint32_t s = f.cur;
+            const uint32_t row = rl(t.srow, s), kto = rl(t.skto, s);
+            const uint32_t wait = trig_wait(t, row, kto, f.k, f.nbits);
+            if (s != 0) {
+                // one evaluation per sample: any always/timeout/msg_complete
+                // trigger due inside the run?
+                if (__ballot(wait < n) == 0) {
+                    f.k = sat_add(f.k, n);
+                    if (e1 >= seg_n) {              // ran into the end of the segment
+                        pos = seg_n;
+                        ci = cia;
+                        canon(t, f);
+                        continue;
+                    }
+                    // the edge sample itself: level flips, prev = b
+                    const uint32_t b2 = b ^ 1u;
+                    const uint64_t ball = __ballot(trig_match(t, row, kto, f.k, b, b2, f.nbits));
+                    pos = e1 + 1;
+                    ci = cia + 1;
+                    f.prev = b2;
+                    if (ball == 0) {                // edge ignored by this state
+                        f.k = sat_add(f.k, 1);
+                        canon(t, f);
+                        continue;
+                    }
+                    r = fsm_fire(t, f, s, (uint32_t)__builtin_ctzll(ball));
+                    at = e1;
+                    dbg_fused++;
+                } else {
+                    const uint32_t w = wave_min(wait);      // < n
+                    f.k = sat_add(f.k, w);
+                    pos += w;
+                    ci = cia;
+                    r = fsm_step(t, f, b);          // fires
+                    at = pos;
+                    pos += 1;
+                }
+            } else {
+                // reset evaluates twice per sample (state_machine.c:526-538)
+                const uint32_t q = wave_min(wait);
+                uint32_t m = q == kNone ? n : (q >> 1);
+                if (m > n) m = n;
+                if (m > 0) {
+                    f.k = sat_add(f.k, 2ull * m);
+                    pos += m;
+                    ci = cia;
+                    canon(t, f);
+                    continue;
+                }
+                r = fsm_step(t, f, b);
+                at = pos;
+                pos += 1;
+                ci = cia;
+            }
+        } else {
+            // ---- the state machine sees a level change at pos -----------------------
+            r = fsm_step(t, f, b);
+            f.prev = b;                             // sm_process: prev_bit = data[i]
+            at = pos;
+            pos += 1;
+            ci = cia;
+        }
+        canon(t, f);
+        if (r == kResOutput) {
+            if (nmsg < p.msg_slots) {
+                if (lane == 0) {
+                    MsgDev mm;
+                    mm.capture = cap;
+                    mm.reserved = 0;
+                    mm.sample = seg_start + at;
+                    // the first (max_bits+7)/8 bytes are the message
+                    const uint32_t nbytes = (t.max_bits + 7u) >> 3;
+                    mm.payload[0] = payload_word(f.d0, 0, nbytes);
+                    mm.payload[1] = payload_word(f.d1, 1, nbytes);
+                    mm.payload[2] = payload_word(f.d2, 2, nbytes);
+                    mm.payload[3] = payload_word(f.d3, 3, nbytes);
+                    msgs[nmsg] = mm;
+                }
+            } else {
+                flags |= 1u;
+            }
+            nmsg++;
+        } else if (r == kResError) {
+            const uint64_t apos = seg_start + at;
+            if (nerr < p.err_slots && lane == 0) errs[nerr] = apos;
+            nerr++;
+            // device.c:646: the rest of this buffer is never fed in
+            const uint64_t in_idx = (uint64_t)p.total_decim * (apos + 1) - 1;
+            const uint64_t buf = in_idx / p.spb;
+            uint64_t nb = buffer_start(buf + 1, p.spb, p.total_decim);
+            if (nb <= apos) nb = apos + 1;
+            if (nb >= seg_end) {
+                skip_out = nb;
+                pos = seg_n;
+                break;
+            }
+            pos = (uint32_t)(nb - seg_start);
+            // first edge at or after pos
+            for (;;) {
+                if (ci >= wbase + 64 || ci < wbase) {
+                    wbase = ci;
+                    OOKD_LOAD_WINDOW()
+                }
+                const uint32_t from = (uint32_t)(ci - wbase);
+                const uint64_t bal = __ballot(lane >= from && ev < pos);
+                const uint32_t cnt = (uint32_t)__popcll(bal);
+                ci += cnt;
+                if (from + cnt < 64) break;         // stopped inside the window
+            }
+        }
+    }
+#undef OOKD_LOAD_WINDOW
+
+    if (p.debug && lane == 0) {
+        p.debug[4 * (size_t)seg + 0] = dbg_turns;
+        p.debug[4 * (size_t)seg + 1] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        p.debug[4 * (size_t)seg + 2] = dbg_fused;
+        p.debug[4 * (size_t)seg + 3] = dbg_loads;
+    }
+    if (lane == 0) {
+        SegState so;
+        so.st.cur = f.cur;
+        so.st.nbits = f.nbits;
+        so.st.k = f.k;
+        so.st.prev = f.prev;
+        so.st.pad = 0;
+        so.st.data[0] = f.d0;
+        so.st.data[1] = f.d1;
+        so.st.data[2] = f.d2;
+        so.st.data[3] = f.d3;
+        so.st.data[4] = f.d4;
+        so.skip_to = skip_out;
+        so.pad = 0;
+        out_cur[seg] = so;
+        p.seg_msg_count[seg] = nmsg;
+        p.seg_err_count[seg] = nerr;
+        if (flags) atomicOr(p.flags, flags);
+    }
+}
+
+// Compacts per-segment messages into one list (single workgroup).
+__global__ __launch_bounds__(1024) void fsm_gather_kernel(const FsmParams p) {
+    __shared__ uint32_t part[1024];
+    __shared__ unsigned long long err_total;
+    const uint32_t nseg = p.num_captures * p.segs_per_cap;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (nseg + 1023u) / 1024u;
+    const uint32_t lo = min(tid * chunk, nseg);
+    const uint32_t hi = min(lo + chunk, nseg);
+    if (tid == 0) err_total = 0;
+    __syncthreads();
+    uint32_t sum = 0;
+    unsigned long long esum = 0;
+    for (uint32_t s = lo; s < hi; ++s) {
+        sum += min(p.seg_msg_count[s], p.msg_slots);
+        esum += p.seg_err_count[s];
+    }
+    if (esum) atomicAdd(&err_total, esum);
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (tid >= d) ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t at = part[tid] - sum;
+    for (uint32_t s = lo; s < hi; ++s) {
+        const uint32_t c = min(p.seg_msg_count[s], p.msg_slots);
+        for (uint32_t i = 0; i < c; ++i) {
+            if (at < p.msg_capacity) p.msgs[at] = p.seg_msgs[(size_t)s * p.msg_slots + i];
+            ++at;
+        }
+    }
+    if (tid == 1023) {
+        p.totals[0] = part[1023];
+        p.totals[1] = err_total;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+
+hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
+    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
+    if (total_blocks == 0) return hipSuccess;
+    const uint32_t wgs = (total_blocks + 3) / 4;        // 4 waves per workgroup
+    const uint32_t groups = (total_blocks + kScanGroup - 1) / kScanGroup;
+    hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(edge_write_kernel, dim3(wgs), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state, hipStream_t stream) {
+    const uint32_t nseg = p.num_captures * p.segs_per_cap;
+    if (nseg == 0) return hipSuccess;
+    FsmStateDev first{};
+    if (first_state) first = *first_state;
+    hipLaunchKernelGGL(fsm_cuts_kernel, dim3(p.num_captures * (p.segs_per_cap + 1)), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(fsm_prepare_kernel, dim3((nseg + 63) / 64), dim3(64), 0, stream, p, first,
+                       first_state ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_fsm_round(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
+                            hipStream_t stream) {
+    const uint32_t nseg = p.num_captures * p.segs_per_cap;
+    if (nseg == 0) return hipSuccess;
+    hipLaunchKernelGGL(fsm_round_kernel, dim3(nseg), dim3(64), 0, stream, p, parity, mode, slot);
+    return hipGetLastError();
+}
+
+hipError_t launch_fsm_gather(const FsmParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(fsm_gather_kernel, dim3(1), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ookd

@@ -15,6 +15,8 @@
 // multiply-adds are written explicitly with __builtin_fmaf.
 #include "kernels.hpp"
 
+#include <utility>
+
 #pragma clang fp contract(off)
 
 namespace ookd {
@@ -94,6 +96,55 @@ __device__ __noinline__ float2 fir1_exact_output(const float2 *lds, uint32_t j_o
     return make_float2(re, im);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+
+// One complex multiply-accumulate acc(re,im) += tap * x(re,im) as a packed
+// fp32 instruction with the tap read from an SGPR pair: `tp` holds two
+// consecutive taps, HI picks which one is broadcast to both halves.  Plain
+// v_fma_f32 issues at half the packed rate on gfx950 (measured: 77 vs 147
+// TFLOP/s), so the packed form is what reaches the fp32 roof.
+//   fused : v_pk_fma_f32                     (one rounding per step)
+//   exact : v_pk_mul_f32 then v_pk_add_f32   (the reference's two roundings)
+template <bool EXACT, bool HI>
+__device__ __forceinline__ void cmac(v2f &acc, v2f tp, v2f x) {
+    if (EXACT) {
+        v2f prod;
+        if (HI) {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(prod) : "s"(tp), "v"(x));
+        } else {
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(prod) : "s"(tp), "v"(x));
+        }
+        asm("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(prod));
+    } else {
+        if (HI) {
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "s"(tp), "v"(x));
+        } else {
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tp), "v"(x));
+        }
+    }
+}
+
+// Compile-time unrolled body of one 32-tap chunk.  Window position W
+// (newest first) feeds output r with tap kk = r - W when 0 <= kk < 32, so
+// every output receives its taps in ascending order (fir.c:313-318).
+template <bool EXACT, int W, int... Rs>
+__device__ __forceinline__ void fir1_wstep(v2f *acc, const v2f *tpair, const v2f *base,
+                                           std::integer_sequence<int, Rs...>) {
+    constexpr int cp = W + kTapChunk;                   // 1 .. 47
+    const v2f x = base[cp + (cp >> 4)];
+    ((void)((Rs - W >= 0 && Rs - W < kTapChunk)
+                ? (cmac<EXACT, ((Rs - W) & 1) != 0>(acc[Rs], tpair[((Rs - W) & 31) >> 1], x), 0)
+                : 0),
+     ...);
+}
+
+template <bool EXACT, int... Ws>
+__device__ __forceinline__ void fir1_chunk(v2f *acc, const v2f *tpair, const v2f *base,
+                                           std::integer_sequence<int, Ws...>) {
+    (fir1_wstep<EXACT, kFirR - 1 - Ws>(acc, tpair, base, std::make_integer_sequence<int, kFirR>{}), ...);
+}
+
 template <bool EXACT>
 __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -109,69 +160,61 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
     // ---- stage the window: slot j <-> input index t0 - Tp + j ----------------
     const uint32_t nvec = (kFirTile + Tp) >> 2;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    for (uint32_t v = tid; v < nvec; v += kFirThreads) {
-        const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
-        float2 s0, s1, s2, s3;
-        if (aligned16 && n >= 0 && (uint64_t)(n + 3) < p.n_valid) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(src + n);
-            s0 = unpack_iq(q.x);
-            s1 = unpack_iq(q.y);
-            s2 = unpack_iq(q.z);
-            s3 = unpack_iq(q.w);
-        } else {
-            s0 = fetch_sample(p, src, nullptr, n);
-            s1 = fetch_sample(p, src, nullptr, n + 1);
-            s2 = fetch_sample(p, src, nullptr, n + 2);
-            s3 = fetch_sample(p, src, nullptr, n + 3);
+    if (aligned16 && t0 >= Tp && t0 + kFirTile <= p.n_valid) {
+        // interior tile: every sample exists, 16 B per lane
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src + (t0 - Tp));
+        for (uint32_t v = tid; v < nvec; v += kFirThreads) {
+            const uint4 q = src4[v];
+            float2 *dst = lds + slot(4 * v);    // 4 slots, never straddle a pad
+            dst[0] = unpack_iq(q.x);
+            dst[1] = unpack_iq(q.y);
+            dst[2] = unpack_iq(q.z);
+            dst[3] = unpack_iq(q.w);
         }
-        float2 *dst = lds + slot(4 * v);        // 4 slots, never straddle a pad
-        dst[0] = s0;
-        dst[1] = s1;
-        dst[2] = s2;
-        dst[3] = s3;
+    } else {
+        for (uint32_t v = tid; v < nvec; v += kFirThreads) {
+            const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
+            float2 *dst = lds + slot(4 * v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = fetch_sample(p, src, nullptr, n + i);
+        }
     }
     __syncthreads();
 
     // ---- accumulate ----------------------------------------------------------
-    float acc_re[R], acc_im[R];
+    v2f acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        acc_re[r] = 0.0f;
-        acc_im[r] = 0.0f;
-    }
+    for (int r = 0; r < R; ++r) acc[r] = (v2f){0.0f, 0.0f};
 
     const uint32_t nchunks = Tp / kTapChunk;
     for (uint32_t c = 0; c < nchunks; ++c) {
-        const float *tp = p.taps + c * kTapChunk;       // wave-uniform => SGPRs
-        float tap[kTapChunk];
-#pragma unroll
-        for (int i = 0; i < kTapChunk; ++i) tap[i] = tp[i];
+        // 32 taps of this chunk -> 16 SGPR pairs
+        const float *tp = p.taps + c * kTapChunk;
+        v8f ta, tb, tc, td;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\t"
+                     "s_load_dwordx8 %1, %4, 0x20\n\t"
+                     "s_load_dwordx8 %2, %4, 0x40\n\t"
+                     "s_load_dwordx8 %3, %4, 0x60\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(ta), "=&s"(tb), "=&s"(tc), "=&s"(td)
+                     : "s"(tp)
+                     : "memory");
+        const v2f tpair[16] = {
+            __builtin_shufflevector(ta, ta, 0, 1), __builtin_shufflevector(ta, ta, 2, 3),
+            __builtin_shufflevector(ta, ta, 4, 5), __builtin_shufflevector(ta, ta, 6, 7),
+            __builtin_shufflevector(tb, tb, 0, 1), __builtin_shufflevector(tb, tb, 2, 3),
+            __builtin_shufflevector(tb, tb, 4, 5), __builtin_shufflevector(tb, tb, 6, 7),
+            __builtin_shufflevector(tc, tc, 0, 1), __builtin_shufflevector(tc, tc, 2, 3),
+            __builtin_shufflevector(tc, tc, 4, 5), __builtin_shufflevector(tc, tc, 6, 7),
+            __builtin_shufflevector(td, td, 0, 1), __builtin_shufflevector(td, td, 2, 3),
+            __builtin_shufflevector(td, td, 4, 5), __builtin_shufflevector(td, td, 6, 7)};
 
         // output r of this lane sits at window slot-index Tp + 16*tid + r; tap
         // kc+kk reads Tp + 16*tid + r - kc - kk = 16*tid + 32*m + (w + 32),
         // w = r - kk, m = (Tp - kc - 32)/32.
         const uint32_t m = nchunks - 1 - c;
-        const float2 *base = lds + 17u * tid + 34u * m;
-#pragma unroll
-        for (int w = R - 1; w >= -(kTapChunk - 1); --w) {
-            const int cp = w + kTapChunk;               // 1 .. 47
-            const float2 x = base[cp + (cp >> 4)];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int kk = r - w;
-                if (kk >= 0 && kk < kTapChunk) {
-                    if (EXACT) {
-                        const float pr = tap[kk] * x.x;
-                        const float pi = tap[kk] * x.y;
-                        acc_re[r] = acc_re[r] + pr;
-                        acc_im[r] = acc_im[r] + pi;
-                    } else {
-                        acc_re[r] = __builtin_fmaf(tap[kk], x.x, acc_re[r]);
-                        acc_im[r] = __builtin_fmaf(tap[kk], x.y, acc_im[r]);
-                    }
-                }
-            }
-        }
+        const v2f *base = reinterpret_cast<const v2f *>(lds + 17u * tid + 34u * m);
+        fir1_chunk<EXACT>(acc, tpair, base, std::make_integer_sequence<int, kFirR + kTapChunk - 1>{});
     }
 
     // ---- threshold, guard band, pack -----------------------------------------
@@ -180,14 +223,14 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
     if (EXACT) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float pw = power_ref(acc_re[r], acc_im[r]);
+            const float pw = power_ref(acc[r].x, acc[r].y);
             mask |= (pw >= p.p_star ? 1u : 0u) << r;
         }
     } else {
         uint32_t unsure = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float pw = power_ref(acc_re[r], acc_im[r]);
+            const float pw = power_ref(acc[r].x, acc[r].y);
             mask |= (pw >= p.p_hi ? 1u : 0u) << r;
             unsure |= ((pw >= p.p_lo && !(pw >= p.p_hi)) ? 1u : 0u) << r;
         }
@@ -217,7 +260,7 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
         float2 *out = reinterpret_cast<float2 *>(p.fir_out) + (uint64_t)cap * p.n_out;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (o0 + r < p.n_out) out[o0 + r] = make_float2(acc_re[r], acc_im[r]);
+            if (o0 + r < p.n_out) out[o0 + r] = make_float2(acc[r].x, acc[r].y);
         }
     }
 
@@ -390,516 +433,6 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t *iq, float2 
 }
 
 // ---------------------------------------------------------------------------
-// edges: count per 4096-bit block, exclusive scan, compact
-// ---------------------------------------------------------------------------
-
-// word of level changes: bit b set <=> sample 64*w+b differs from its
-// predecessor (the sample before a capture counts as 0, as record_dig's
-// first line does for sample 0, ookiedokie.c:150-153).
-__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w) {
-    const uint64_t cur = words[w];
-    const uint64_t prev_top = (w == 0) ? 0ull : (words[w - 1] >> 63);
-    return cur ^ ((cur << 1) | prev_top);
-}
-
-__global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
-    if (wave >= total_blocks) return;
-    const uint32_t cap = wave / p.blocks_per_cap;
-    const uint32_t blk = wave % p.blocks_per_cap;
-    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id());
-    uint32_t c = (uint32_t)__popcll(e);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if (lane_id() == 0) p.blk_count[wave] = c;
-}
-
-// single workgroup, 1024 lanes: exclusive scan of blk_count into blk_offset[0..n]
-__global__ __launch_bounds__(1024) void edge_scan_kernel(const EdgeParams p) {
-    __shared__ uint32_t part[1024];
-    const uint32_t n = p.num_captures * p.blocks_per_cap;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (n + 1023u) / 1024u;
-    const uint32_t lo = min(tid * chunk, n);
-    const uint32_t hi = min(lo + chunk, n);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += p.blk_count[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (tid >= d) ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum;     // exclusive prefix of this lane's chunk
-    for (uint32_t i = lo; i < hi; ++i) {
-        p.blk_offset[i] = run;
-        run += p.blk_count[i];
-    }
-    if (tid == 1023) {
-        p.blk_offset[n] = part[1023];
-        if ((uint64_t)part[1023] > p.edge_capacity) *p.overflow = 1;
-    }
-}
-
-__global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
-    if (wave >= total_blocks) return;
-    if (p.blk_count[wave] == 0) return;
-    const uint32_t cap = wave / p.blocks_per_cap;
-    const uint32_t blk = wave % p.blocks_per_cap;
-    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-    const uint64_t w = (uint64_t)blk * kBlockWords + lane_id();
-    uint64_t e = change_word(words, w);
-    const uint32_t c = (uint32_t)__popcll(e);
-    // exclusive prefix over the wave
-    uint32_t inc = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(inc, d);
-        if ((int)lane_id() >= d) inc += v;
-    }
-    uint64_t at = (uint64_t)p.blk_offset[wave] + (inc - c);
-    while (e) {
-        const int b = __ffsll((long long)e) - 1;
-        if (at < p.edge_capacity) p.edges[at] = w * 64 + (uint64_t)b;
-        ++at;
-        e &= e - 1;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// symbol state machine over the edge list
-// ---------------------------------------------------------------------------
-//
-// Integer restatement of handle_rx_triggers / process (state_machine.c:
-// 421-539).  `k` = number of elapsed_us increments since it was last zeroed;
-// the host turned every duration window / timeout into a range of k by
-// replaying the reference's double accumulation, so the tests below are the
-// reference's float comparisons exactly.
-
-enum { kCondAlways = 1, kCondPulseStart, kCondPulseEnd, kCondTimeout, kCondMsgComplete };
-enum { kActNone = 1, kActAppend0, kActAppend1, kActOutput };
-enum { kResError = -1, kResNone = 0, kResOutput = 1 };
-
-struct Fsm {
-    const FsmTablesDev *t;      // LDS copy
-    uint32_t cur, nbits, prev;
-    uint64_t k;
-    uint64_t data[kPayloadWords];
-};
-
-__device__ __forceinline__ bool in_range(uint64_t k, uint64_t lo, uint64_t hi) {
-    return k >= lo && k <= hi;
-}
-
-// state_machine.c:421-519
-__device__ int fsm_eval(Fsm &f, uint32_t b) {
-    const FsmTablesDev *t = f.t;
-    const uint32_t s = f.cur;
-    int fired = -1;
-    bool edge = false;
-    for (uint32_t i = t->trig_begin[s]; i < t->trig_begin[s + 1] && fired < 0; ++i) {
-        if (!in_range(f.k, t->trig_kmin[i], t->trig_kmax[i])) continue;    // :119-133
-        switch (t->trig_cond[i]) {
-        case kCondAlways:
-            fired = (int)i;
-            break;
-        case kCondPulseStart:
-            if (!f.prev && b) {
-                fired = (int)i;
-                edge = true;
-            }
-            break;
-        case kCondPulseEnd:
-            if (f.prev && !b) {
-                fired = (int)i;
-                edge = true;
-            }
-            break;
-        case kCondTimeout:
-            if (f.k >= t->state_kto[s]) fired = (int)i;     // kto = MAX when no timeout
-            break;
-        case kCondMsgComplete:
-            if (f.nbits >= t->max_bits) fired = (int)i;
-            break;
-        default:
-            break;
-        }
-    }
-    if (fired < 0) {
-        f.k += 1;                                           // :513-515
-        return kResNone;
-    }
-    int result = kResNone;
-    const bool ok = !edge || in_range(f.k, t->state_kmin[s], t->state_kmax[s]);   // :100-117
-    if (ok) {
-        const uint32_t act = t->trig_action[fired];
-        if (act == kActAppend0 || act == kActAppend1) {
-            // :365-385 stores while num_bits <= max_bits, always counts
-            if (f.nbits <= t->max_bits) {
-                const uint32_t wi = f.nbits >> 6;
-                const uint64_t m = 1ull << (f.nbits & 63u);
-                if (wi < kPayloadWords) {
-                    if (act == kActAppend1) f.data[wi] |= m;
-                    else f.data[wi] &= ~m;
-                }
-            }
-            f.nbits += 1;
-        } else if (act == kActOutput) {
-            result = kResOutput;
-        }
-        f.cur = t->trig_next[fired];
-    } else {
-        result = kResError;
-        f.cur = 0;                                          // :505-509
-    }
-    f.k = 0;                                                // :511
-    return result;
-}
-
-// state_machine.c:521-539: reset clears the payload and is evaluated, then
-// the (possibly new) state is evaluated on the same sample.
-__device__ int fsm_step(Fsm &f, uint32_t b) {
-    if (f.cur == 0) {
-        f.nbits = 0;
-        // memset(data, 0, (max_bits+7)/8); the spare word past it is never output
-        for (int i = 0; i < kPayloadWords; ++i) f.data[i] = 0;
-        const int r = fsm_eval(f, b);
-        if (r != kResNone) return r;
-    }
-    return fsm_eval(f, b);
-}
-
-// Number of upcoming trigger EVALUATIONS (at k, k+1, ...) that certainly do
-// not fire while the input level stays constant (b == prev, so pulse
-// triggers cannot fire).  UINT64_MAX = never.
-__device__ uint64_t fsm_quiet_evals(const Fsm &f) {
-    const FsmTablesDev *t = f.t;
-    const uint32_t s = f.cur;
-    uint64_t best = ~0ull;
-    for (uint32_t i = t->trig_begin[s]; i < t->trig_begin[s + 1]; ++i) {
-        uint64_t lo = t->trig_kmin[i];
-        const uint64_t hi = t->trig_kmax[i];
-        const uint32_t c = t->trig_cond[i];
-        if (c == kCondAlways) {
-        } else if (c == kCondTimeout) {
-            const uint64_t kto = t->state_kto[s];
-            if (kto == ~0ull) continue;
-            if (kto > lo) lo = kto;
-        } else if (c == kCondMsgComplete) {
-            if (f.nbits < t->max_bits) continue;
-        } else {
-            continue;
-        }
-        const uint64_t first = f.k > lo ? f.k : lo;         // first k >= max(k, lo)
-        if (first > hi) continue;
-        const uint64_t wait = first - f.k;
-        if (wait < best) best = wait;
-    }
-    return best;
-}
-
-// First decimated index of buffer `buf`: floor(buf * spb / D)
-// (decimated sample j comes from input D*(j+1)-1).
-__device__ __forceinline__ uint64_t buffer_start(uint64_t buf, uint32_t spb, uint32_t D) {
-    return (buf * (uint64_t)spb) / D;      // buf*spb ~ input samples, fits 64 bits
-}
-
-constexpr int kEdgeWin = 256;
-
-__global__ __launch_bounds__(64) void fsm_prepare_kernel(const FsmParams p, const FsmStateDev first,
-                                                         int have_first) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nseg = p.num_captures * p.segs_per_cap;
-    if (seg >= nseg) return;
-    const uint32_t cap = seg / p.segs_per_cap;
-    const uint32_t ls = seg % p.segs_per_cap;
-    FsmStateDev st;
-    st.cur = 0;
-    st.nbits = 0;
-    st.k = 0;
-    st.prev = 0;
-    st.pad = 0;
-    for (int i = 0; i < kPayloadWords; ++i) st.data[i] = 0;
-    if (ls == 0) {
-        if (have_first) st = first;
-    } else {
-        // speculative: reset state, previous bit = the sample before the segment
-        const uint64_t start = buffer_start((uint64_t)ls * p.seg_buffers, p.spb, p.total_decim);
-        if (start > 0 && start <= p.n_out) {
-            const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-            st.prev = (uint32_t)((words[(start - 1) >> 6] >> ((start - 1) & 63)) & 1ull);
-        }
-    }
-    p.state_in[seg] = st;
-    p.seg_msg_count[seg] = 0;
-    p.seg_err_count[seg] = 0;
-}
-
-__device__ __forceinline__ bool state_equal(const FsmStateDev &a, const FsmStateDev &b) {
-    bool eq = a.cur == b.cur && a.nbits == b.nbits && a.k == b.k && a.prev == b.prev;
-    for (int i = 0; i < kPayloadWords; ++i) eq = eq && a.data[i] == b.data[i];
-    return eq;
-}
-
-// One wave per segment; lane 0 walks the state machine, all lanes fetch
-// edges cooperatively into an LDS window.
-// mode 0: run every segment (fresh run).  mode 1: rerun only segments whose
-// incoming state (the previous segment's outgoing state of the last round)
-// changed.  mode 2: as 1, and a capture's first segment reruns too (its
-// incoming state was just replaced by the host: shard refine).
-__global__ __launch_bounds__(64) void fsm_run_kernel(const FsmParams p, uint32_t parity, uint32_t mode,
-                                                     uint32_t slot) {
-    __shared__ FsmTablesDev tab;
-    __shared__ uint64_t win[kEdgeWin];
-    __shared__ uint64_t sh_ci;
-    __shared__ uint64_t sh_pos;
-    __shared__ int sh_done;
-
-    const uint32_t seg = blockIdx.x;
-    const uint32_t nseg = p.num_captures * p.segs_per_cap;
-    const uint32_t cap = seg / p.segs_per_cap;
-    const uint32_t ls = seg % p.segs_per_cap;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t par = parity & 1u;
-    FsmStateDev *out_cur = p.state_out + (size_t)par * nseg;
-    const FsmStateDev *out_prev = p.state_out + (size_t)(par ^ 1u) * nseg;
-
-    // ---- does this segment need to run? --------------------------------------
-    if (mode != 0) {
-        bool rerun = false;
-        if (ls != 0) {
-            const FsmStateDev nin = out_prev[seg - 1];
-            rerun = !state_equal(nin, p.state_in[seg]);
-            if (rerun && lane == 0) p.state_in[seg] = nin;
-        } else {
-            rerun = (mode == 2);
-        }
-        if (!rerun) {
-            if (lane == 0) out_cur[seg] = out_prev[seg];
-            return;
-        }
-        if (lane == 0) atomicAdd(&p.changed[slot], 1u);
-        __syncthreads();
-    }
-
-    // ---- tables to LDS -----------------------------------------------------------
-    {
-        const uint32_t *srcw = reinterpret_cast<const uint32_t *>(p.tables);
-        uint32_t *dstw = reinterpret_cast<uint32_t *>(&tab);
-        for (uint32_t i = lane; i < sizeof(FsmTablesDev) / 4; i += 64) dstw[i] = srcw[i];
-    }
-
-    const uint64_t seg_start = min(buffer_start((uint64_t)ls * p.seg_buffers, p.spb, p.total_decim), p.n_out);
-    const uint64_t seg_end = (ls + 1 == p.segs_per_cap)
-                                 ? p.n_out
-                                 : min(buffer_start((uint64_t)(ls + 1) * p.seg_buffers, p.spb, p.total_decim),
-                                       p.n_out);
-    const uint32_t blk0 = cap * p.blocks_per_cap;
-    const uint64_t cap_e0 = p.blk_offset[blk0];
-    const uint64_t ne = (uint64_t)p.blk_offset[blk0 + p.blocks_per_cap] - cap_e0;   // edges of this capture
-    const uint64_t *edges = p.edges + cap_e0;
-
-    // ---- first edge at or after seg_start (capture-local index) ------------------
-    uint64_t ci;
-    {
-        const uint64_t blk = min(seg_start >> 12, (uint64_t)p.blocks_per_cap - 1);
-        uint64_t i = (uint64_t)p.blk_offset[blk0 + blk] - cap_e0;
-        const uint64_t iend = (uint64_t)p.blk_offset[blk0 + blk + 1] - cap_e0;
-        // count edges of that block below seg_start, 64 at a time
-        uint64_t below = 0;
-        for (; i < iend; i += 64) {
-            const uint64_t idx = i + lane;
-            const bool lt = idx < iend && edges[idx] < seg_start;
-            below += (uint64_t)__popcll(__ballot(lt));
-        }
-        ci = ((uint64_t)p.blk_offset[blk0 + blk] - cap_e0) + below;
-    }
-    __syncthreads();
-
-    Fsm f;
-    uint64_t pos = seg_start;
-    uint32_t nmsg = 0, nerr = 0;
-    uint32_t flags = 0;
-    if (lane == 0) {
-        const FsmStateDev st = p.state_in[seg];
-        f.t = &tab;
-        f.cur = st.cur;
-        f.nbits = st.nbits;
-        f.prev = st.prev;
-        f.k = st.k;
-        for (int i = 0; i < kPayloadWords; ++i) f.data[i] = st.data[i];
-        sh_ci = ci;
-        sh_done = (pos >= seg_end) ? 1 : 0;
-    }
-    __syncthreads();
-
-    MsgDev *msgs = p.seg_msgs + (size_t)seg * p.msg_slots;
-    uint64_t *errs = p.seg_errs + (size_t)seg * p.err_slots;
-
-    while (!sh_done) {
-        // refill the window with edges[win_base .. win_base + kEdgeWin)
-        const uint64_t win_base = sh_ci;
-        for (uint32_t q = lane; q < kEdgeWin; q += 64) {
-            const uint64_t idx = win_base + q;
-            win[q] = idx < ne ? edges[idx] : ~0ull;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            ci = win_base;
-            // needs win[ci - win_base] and win[ci + 1 - win_base]
-            while (pos < seg_end && ci + 1 < win_base + kEdgeWin) {
-                const uint64_t e0 = win[ci - win_base];
-                const bool at_edge = (e0 == pos);
-                const uint64_t cia = ci + (at_edge ? 1 : 0);
-                const uint32_t b = (uint32_t)(cia & 1ull);
-                if (b == f.prev) {
-                    // constant input: skip samples that cannot fire a trigger
-                    const uint64_t e1 = win[cia - win_base];
-                    const uint64_t run_end = e1 < seg_end ? e1 : seg_end;
-                    const uint64_t n = run_end - pos;
-                    const uint64_t quiet = fsm_quiet_evals(f);
-                    uint64_t m;
-                    if (f.cur == 0) {
-                        m = quiet >> 1;                 // two evaluations per sample in reset
-                        if (m > n) m = n;
-                        if (m > 0) f.k += 2 * m;
-                    } else {
-                        m = quiet < n ? quiet : n;
-                        if (m > 0) f.k += m;
-                    }
-                    if (m > 0) {
-                        pos += m;
-                        ci = cia;
-                        continue;
-                    }
-                }
-                const int r = fsm_step(f, b);
-                f.prev = b;                             // sm_process: prev_bit = data[i]
-                if (r == kResOutput) {
-                    if (nmsg < p.msg_slots) {
-                        MsgDev mm;
-                        mm.capture = cap;
-                        mm.reserved = 0;
-                        mm.sample = pos;
-                        // the first (max_bits+7)/8 bytes are the message
-                        const uint32_t nbytes = (tab.max_bits + 7u) >> 3;
-                        for (uint32_t i = 0; i < 4; ++i) {
-                            uint64_t v = f.data[i];
-                            if (8 * i >= nbytes) v = 0;
-                            else if (8 * (i + 1) > nbytes) v &= (1ull << ((nbytes - 8 * i) * 8)) - 1ull;
-                            mm.payload[i] = v;
-                        }
-                        msgs[nmsg] = mm;
-                    } else {
-                        flags |= 1u;
-                    }
-                    nmsg++;
-                    pos += 1;
-                    ci = cia;
-                } else if (r == kResError) {
-                    if (nerr < p.err_slots) errs[nerr] = pos;
-                    nerr++;
-                    // device.c:646: the rest of this buffer is never fed in
-                    const uint64_t in_idx = (uint64_t)p.total_decim * (pos + 1) - 1;
-                    const uint64_t buf = in_idx / p.spb;
-                    const uint64_t nb = buffer_start(buf + 1, p.spb, p.total_decim);
-                    pos = nb > pos ? nb : pos + 1;
-                    ci = cia;
-                    // first edge at or after pos
-                    while (ci + 1 < win_base + kEdgeWin && win[ci - win_base] < pos) ci++;
-                    if (win[ci - win_base] < pos) break;    // ran off the window: refill
-                } else {
-                    pos += 1;
-                    ci = cia;
-                }
-            }
-            // after a window break caused by the skip loop, make sure ci is exact
-            sh_ci = ci;
-            sh_done = (pos >= seg_end) ? 1 : 0;
-        }
-        __syncthreads();
-        // an error skip can leave win[ci] < pos with the window exhausted: advance
-        // through the list cooperatively until the first edge >= pos
-        if (!sh_done) {
-            if (lane == 0) sh_pos = pos;
-            __syncthreads();
-            const uint64_t target = sh_pos;
-            uint64_t c2 = sh_ci;
-            for (;;) {
-                const uint64_t idx = c2 + lane;
-                const bool lt = idx < ne && edges[idx] < target;
-                const uint64_t bal = __ballot(lt);
-                c2 += (uint64_t)__popcll(bal);
-                if (bal != ~0ull) break;
-            }
-            __syncthreads();
-            if (lane == 0) sh_ci = c2;
-            __syncthreads();
-        }
-    }
-
-    if (lane == 0) {
-        FsmStateDev st;
-        st.cur = f.cur;
-        st.nbits = f.nbits;
-        st.k = f.k;
-        st.prev = f.prev;
-        st.pad = 0;
-        for (int i = 0; i < kPayloadWords; ++i) st.data[i] = f.data[i];
-        out_cur[seg] = st;
-        p.seg_msg_count[seg] = nmsg;
-        p.seg_err_count[seg] = nerr;
-        if (flags) atomicOr(p.flags, flags);
-    }
-}
-
-// Compacts per-segment messages into one list (single workgroup).
-__global__ __launch_bounds__(1024) void fsm_gather_kernel(const FsmParams p) {
-    __shared__ uint32_t part[1024];
-    __shared__ unsigned long long err_total;
-    const uint32_t nseg = p.num_captures * p.segs_per_cap;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (nseg + 1023u) / 1024u;
-    const uint32_t lo = min(tid * chunk, nseg);
-    const uint32_t hi = min(lo + chunk, nseg);
-    if (tid == 0) err_total = 0;
-    __syncthreads();
-    uint32_t sum = 0;
-    unsigned long long esum = 0;
-    for (uint32_t s = lo; s < hi; ++s) {
-        sum += min(p.seg_msg_count[s], p.msg_slots);
-        esum += p.seg_err_count[s];
-    }
-    if (esum) atomicAdd(&err_total, esum);
-    part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (tid >= d) ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint64_t at = part[tid] - sum;
-    for (uint32_t s = lo; s < hi; ++s) {
-        const uint32_t c = min(p.seg_msg_count[s], p.msg_slots);
-        for (uint32_t i = 0; i < c; ++i) {
-            if (at < p.msg_capacity) p.msgs[at] = p.seg_msgs[(size_t)s * p.msg_slots + i];
-            ++at;
-        }
-    }
-    if (tid == 1023) {
-        p.totals[0] = part[1023];
-        p.totals[1] = err_total;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // synthetic capture generator
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64_t num_runs, uint64_t seed,
@@ -1024,39 +557,6 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         }
     }
     return launch_front_generic(p, num_captures, stream);
-}
-
-hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
-    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
-    if (total_blocks == 0) return hipSuccess;
-    const uint32_t wgs = (total_blocks + 3) / 4;        // 4 waves per workgroup
-    hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(edge_scan_kernel, dim3(1), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(edge_write_kernel, dim3(wgs), dim3(256), 0, stream, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state, hipStream_t stream) {
-    const uint32_t nseg = p.num_captures * p.segs_per_cap;
-    if (nseg == 0) return hipSuccess;
-    FsmStateDev first{};
-    if (first_state) first = *first_state;
-    hipLaunchKernelGGL(fsm_prepare_kernel, dim3((nseg + 63) / 64), dim3(64), 0, stream, p, first,
-                       first_state ? 1 : 0);
-    return hipGetLastError();
-}
-
-hipError_t launch_fsm_iteration(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
-                                hipStream_t stream) {
-    const uint32_t nseg = p.num_captures * p.segs_per_cap;
-    if (nseg == 0) return hipSuccess;
-    hipLaunchKernelGGL(fsm_run_kernel, dim3(nseg), dim3(64), 0, stream, p, parity, mode, slot);
-    return hipGetLastError();
-}
-
-hipError_t launch_fsm_gather(const FsmParams &p, uint32_t, hipStream_t stream) {
-    hipLaunchKernelGGL(fsm_gather_kernel, dim3(1), dim3(1024), 0, stream, p);
-    return hipGetLastError();
 }
 
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream) {

@@ -17,9 +17,6 @@ constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
 constexpr int kBlockWords = 64;         // one edge block = 64 words = 4096 bits
 constexpr int kPayloadWords = 5;        // 4 x u64 payload + 1 spare (bit index == max_bits)
-constexpr int kMaxStates = 64;
-constexpr int kMaxTriggers = 256;
-
 // ---- front end -------------------------------------------------------------
 
 struct FirStageDev {
@@ -60,13 +57,16 @@ size_t generic_lds_bytes(const FrontParams &p);
 
 // ---- edges -----------------------------------------------------------------
 
+constexpr int kScanGroup = 1024;        // blocks per first-level scan group
+
 struct EdgeParams {
     const uint64_t *bits;
     uint64_t words_per_cap;
     uint32_t num_captures;
     uint32_t blocks_per_cap;    // words_per_cap / kBlockWords
     uint32_t *blk_count;        // [captures * blocks_per_cap]
-    uint32_t *blk_offset;       // exclusive prefix, same size + 1
+    uint32_t *blk_offset;       // exclusive prefix over all blocks, size + 1
+    uint32_t *group_total;      // [ceil(blocks / kScanGroup)] scratch
     uint64_t *edges;            // capture-local decimated indices
     uint64_t edge_capacity;
     uint32_t *overflow;         // set to 1 when total edges > capacity
@@ -75,14 +75,21 @@ struct EdgeParams {
 hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);
 
 // ---- state machine ---------------------------------------------------------
+//
+// The kernel keeps the tables in VGPR lanes (lane i = trigger i / state i),
+// hence at most 64 of each.
+
+constexpr int kMaxStates = 64;
+constexpr int kMaxTriggers = 64;
 
 struct FsmTablesDev {
-    uint32_t num_states, max_bits, num_triggers, pad;
+    uint32_t num_states, max_bits, num_triggers;
+    uint32_t quiet_state;       // state every trajectory settles in on a long 0 level
     uint64_t state_kmin[kMaxStates], state_kmax[kMaxStates], state_kto[kMaxStates];
-    uint32_t trig_begin[kMaxStates + 1];
+    uint32_t state_tbeg[kMaxStates], state_tend[kMaxStates];
+    uint32_t state_flags[kMaxStates];       // bit 0: k never influences this state
     uint64_t trig_kmin[kMaxTriggers], trig_kmax[kMaxTriggers];
-    uint32_t trig_next[kMaxTriggers];
-    uint8_t trig_cond[kMaxTriggers], trig_action[kMaxTriggers];
+    uint32_t trig_info[kMaxTriggers];       // cond | action << 8 | next << 16
 };
 
 struct FsmStateDev {            // same layout as ookd_fsm_state
@@ -92,6 +99,13 @@ struct FsmStateDev {            // same layout as ookd_fsm_state
     uint64_t data[kPayloadWords];
 };
 static_assert(sizeof(FsmStateDev) == 64, "FsmStateDev layout");
+
+struct SegState {               // state carried between segments of one capture
+    FsmStateDev st;
+    uint64_t skip_to;           // samples below this index are not fed in (device.c:646)
+    uint64_t pad;
+};
+static_assert(sizeof(SegState) == 80, "SegState layout");
 
 struct MsgDev {                 // same layout as ookd_message
     uint32_t capture, reserved;
@@ -111,28 +125,32 @@ struct FsmParams {
     uint64_t n_out;             // decimated samples per capture
     uint32_t spb;               // input samples per buffer
     uint32_t total_decim;
-    uint32_t seg_buffers;       // buffers per segment
+    uint64_t seg_len;           // nominal decimated samples per segment
     uint32_t segs_per_cap;
     uint32_t msg_slots, err_slots;
-    FsmStateDev *state_in;      // [segs]
-    FsmStateDev *state_out;     // [2][segs] ping-pong by iteration parity
+    uint64_t *seg_bounds;       // [captures][segs_per_cap + 1]
+    SegState *state_in;         // [segs]
+    SegState *state_out;        // [2][segs] ping-pong by round parity
     MsgDev *seg_msgs;           // [segs][msg_slots]
     uint32_t *seg_msg_count;    // [segs]
     uint64_t *seg_errs;         // [segs][err_slots]
     uint32_t *seg_err_count;    // [segs]
-    uint32_t *changed;          // [iterations]
+    uint32_t *changed;          // [rounds of one batch]
     uint32_t *flags;            // bit0: message slot overflow
     // compaction
     MsgDev *msgs;               // [msg_capacity]
     uint64_t msg_capacity;
     uint64_t *totals;           // [0] messages, [1] errors
+    uint64_t *debug;            // optional [segs][4]: loop turns, cycles, fused edges, window loads
 };
 
 hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state,
                               hipStream_t stream);
-hipError_t launch_fsm_iteration(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
-                                hipStream_t stream);
-hipError_t launch_fsm_gather(const FsmParams &p, uint32_t final_parity, hipStream_t stream);
+// mode 0: run every segment; 1: rerun segments whose incoming state changed;
+// 2: as 1 and the first segment of each capture reruns (shard refine).
+hipError_t launch_fsm_round(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
+                            hipStream_t stream);
+hipError_t launch_fsm_gather(const FsmParams &p, hipStream_t stream);
 
 // ---- unpack (backend rx) ----------------------------------------------------
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream);

@@ -3,6 +3,7 @@
 // src/ookiedokie.c:243-288, for whole captures resident in HBM).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -114,6 +115,86 @@ void guard_band(const std::vector<float> &taps, float p_star, float &p_lo, float
     }
 }
 
+// Which state does every trajectory settle in while the input stays low?
+// Walks the tables from reset with no edges: only always / timeout /
+// msg_complete triggers can fire.  Used only as the ASSUMED incoming state of
+// a state machine segment (a wrong guess costs fix-point rounds, never
+// correctness).
+uint32_t quiet_state(const ookd_device &d) {
+    const uint64_t NONE = ~0ull;
+    uint32_t cur = 0, nbits = 0;
+    uint64_t k = 0;
+    const size_t ns = d.state_duration_us.size();
+    for (size_t step = 0; step < 4 * ns + 8; ++step) {
+        int fire = -1;
+        uint64_t best = NONE;
+        for (uint32_t t = d.trig_begin[cur]; t < d.trig_begin[cur + 1]; ++t) {
+            uint64_t lo = d.trig_kmin[t];
+            const uint8_t c = d.trig_cond[t];
+            if (c == 4) {               // timeout
+                if (d.state_kto[cur] == NONE) continue;
+                lo = std::max(lo, d.state_kto[cur]);
+            } else if (c == 5) {        // msg_complete
+                if (nbits < d.num_bits) continue;
+            } else if (c != 1) {        // pulse triggers need an edge
+                continue;
+            }
+            const uint64_t first = std::max(k, lo);
+            if (first > d.trig_kmax[t]) continue;
+            if (first - k < best) {     // earliest in time, then first in file order
+                best = first - k;
+                fire = (int)t;
+            }
+        }
+        if (fire < 0) return cur;
+        const uint8_t act = d.trig_action[fire];
+        if (act == 2 || act == 3) nbits++;
+        cur = d.trig_next[fire];
+        if (cur == 0) nbits = 0;
+        k = 0;
+    }
+    return 0;
+}
+
+void fill_fsm_tables(const ookd_device &d, FsmTablesDev &t) {
+    const uint64_t NONE = ~0ull;
+    const size_t ns = d.state_duration_us.size();
+    const size_t nt = d.trig_cond.size();
+    t.num_states = (uint32_t)ns;
+    t.max_bits = d.num_bits;
+    t.num_triggers = (uint32_t)nt;
+    for (size_t i = 0; i < (size_t)kMaxTriggers; ++i) {
+        t.trig_kmin[i] = 1;             // empty window: never matches
+        t.trig_kmax[i] = 0;
+    }
+    for (size_t s = 0; s < (size_t)kMaxStates; ++s) {
+        t.state_kmax[s] = NONE;
+        t.state_kto[s] = NONE;
+    }
+    for (size_t s = 0; s < ns; ++s) {
+        t.state_kmin[s] = d.state_kmin[s];
+        t.state_kmax[s] = d.state_kmax[s];
+        t.state_kto[s] = d.state_kto[s];
+        t.state_tbeg[s] = d.trig_begin[s];
+        t.state_tend[s] = d.trig_begin[s + 1];
+        // k is irrelevant in a state with no duration, no live timeout and no
+        // trigger duration windows
+        bool irrelevant = d.state_kmin[s] == 0 && d.state_kmax[s] == NONE;
+        for (uint32_t i = d.trig_begin[s]; i < d.trig_begin[s + 1]; ++i) {
+            if (d.trig_kmin[i] != 0 || d.trig_kmax[i] != NONE) irrelevant = false;
+            if (d.trig_cond[i] == 4 && d.state_kto[s] != NONE) irrelevant = false;
+        }
+        t.state_flags[s] = irrelevant ? 1u : 0u;
+    }
+    for (size_t i = 0; i < nt; ++i) {
+        t.trig_kmin[i] = d.trig_kmin[i];
+        t.trig_kmax[i] = d.trig_kmax[i];
+        t.trig_info[i] = (uint32_t)d.trig_cond[i] | ((uint32_t)d.trig_action[i] << 8) |
+                         ((uint32_t)d.trig_next[i] << 16);
+    }
+    t.quiet_state = quiet_state(d);
+}
+
 uint64_t gcd64(uint64_t a, uint64_t b) {
     while (b) {
         uint64_t t = a % b;
@@ -152,19 +233,21 @@ struct ookd_rx {
     uint32_t max_captures = 1;
     uint64_t max_n_in = 0, max_n_out = 0, max_words = 0;
     uint32_t max_blocks = 0, max_segs_per_cap = 0;
-    uint32_t seg_buffers = 0, msg_slots = 0, err_slots = 0;
+    uint64_t seg_len = 0;
+    uint32_t msg_slots = 0, err_slots = 0;
     uint64_t edge_capacity = 0, msg_capacity = 0;
 
     DevBuf<uint64_t> d_bits;
     DevBuf<float> d_fir;
     DevBuf<int16_t> d_halo;
-    DevBuf<uint32_t> d_blk_count, d_blk_offset;
-    DevBuf<uint64_t> d_edges;
-    DevBuf<FsmStateDev> d_state_in, d_state_out;
+    DevBuf<uint32_t> d_blk_count, d_blk_offset, d_group_total;
+    DevBuf<uint64_t> d_edges, d_seg_bounds;
+    DevBuf<SegState> d_state_in, d_state_out;
     DevBuf<MsgDev> d_seg_msgs, d_msgs;
     DevBuf<uint32_t> d_seg_msg_count, d_seg_err_count;
     DevBuf<uint64_t> d_seg_errs;
     DevBuf<ResultHeader> d_hdr;
+    DevBuf<uint64_t> d_debug;
     DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
 
     ResultHeader *h_hdr = nullptr;  // pinned
@@ -188,6 +271,8 @@ struct ookd_rx {
         d_halo.release();
         d_blk_count.release();
         d_blk_offset.release();
+        d_group_total.release();
+        d_seg_bounds.release();
         d_edges.release();
         d_state_in.release();
         d_state_out.release();
@@ -197,6 +282,7 @@ struct ookd_rx {
         d_seg_err_count.release();
         d_seg_errs.release();
         d_hdr.release();
+        d_debug.release();
         d_stage_in.release();
         if (h_hdr) (void)hipHostFree(h_hdr);
         if (h_msgs) (void)hipHostFree(h_msgs);
@@ -214,8 +300,7 @@ struct ookd_rx {
         const uint64_t tiles = (n_out + kFirTile - 1) / kFirTile;
         words = tiles * (kFirTile / 64);
         blocks = (uint32_t)(words / kBlockWords);
-        const uint64_t nbuf = (n_in + spb - 1) / spb;
-        segs = (uint32_t)((nbuf + seg_buffers - 1) / seg_buffers);
+        segs = (uint32_t)((n_out + seg_len - 1) / seg_len);
         if (segs == 0 && n_out > 0) segs = 1;
     }
 
@@ -247,6 +332,7 @@ struct ookd_rx {
         e.blocks_per_cap = run_blocks;
         e.blk_count = d_blk_count.p;
         e.blk_offset = d_blk_offset.p;
+        e.group_total = d_group_total.p;
         e.edges = d_edges.p;
         e.edge_capacity = edge_capacity;
         e.overflow = &d_hdr.p->edge_overflow;
@@ -265,8 +351,9 @@ struct ookd_rx {
         f.n_out = run_n_out;
         f.spb = cfg.samples_per_buffer;
         f.total_decim = total_decim;
-        f.seg_buffers = seg_buffers;
+        f.seg_len = seg_len;
         f.segs_per_cap = run_segs_per_cap;
+        f.seg_bounds = d_seg_bounds.p;
         f.msg_slots = msg_slots;
         f.err_slots = err_slots;
         f.state_in = d_state_in.p;
@@ -280,6 +367,7 @@ struct ookd_rx {
         f.msgs = d_msgs.p;
         f.msg_capacity = msg_capacity;
         f.totals = d_hdr.p->totals;
+        f.debug = d_debug.p;
         return f;
     }
 
@@ -315,6 +403,8 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
         iter_next = 0;
     } else if (force_first) {
         // refine: new incoming state for segment 0 of the (single) capture
+        // (the FsmStateDev is the leading member of SegState; skip_to stays 0:
+        // shards start on buffer boundaries)
         HIPCHK(hipMemcpyAsync(d_state_in.p, first, sizeof(FsmStateDev), hipMemcpyHostToDevice, stream));
     }
     uint32_t rounds = 0;
@@ -323,7 +413,7 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
         HIPCHK(hipMemsetAsync(d_hdr.p->changed, 0, sizeof(uint32_t) * kIterBatch, stream));
         const uint32_t batch_mode0 = mode;
         for (uint32_t i = 0; i < kIterBatch; ++i) {
-            HIPCHK(launch_fsm_iteration(fp, iter_next & 1u, mode, i, stream));
+            HIPCHK(launch_fsm_round(fp, iter_next & 1u, mode, i, stream));
             iter_next++;
             mode = 1;
         }
@@ -331,6 +421,11 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
                               hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         rounds += kIterBatch;
+        if (getenv("OOKD_DEBUG")) {
+            fprintf(stderr, "[ookd] fsm batch mode0=%u changed:", batch_mode0);
+            for (uint32_t i = 0; i < kIterBatch; ++i) fprintf(stderr, " %u", h_hdr->changed[i]);
+            fprintf(stderr, " (segments %u)\n", run_caps * run_segs_per_cap);
+        }
         // converged once an incremental round reran nothing (a mode-0 round
         // reruns everything and reports no count; a mode-2 round counts the
         // forced first segments)
@@ -345,9 +440,27 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
             return OOKD_ERR_ARG;
         }
     }
+    if (d_debug.p) {
+        const size_t nseg = (size_t)run_caps * run_segs_per_cap;
+        std::vector<uint64_t> dbg(nseg * 4);
+        HIPCHK(hipMemcpy(dbg.data(), d_debug.p, dbg.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t turns = 0, cyc = 0, fused = 0, loads = 0, maxcyc = 0, maxturns = 0;
+        for (size_t i = 0; i < nseg; ++i) {
+            turns += dbg[4 * i];
+            cyc += dbg[4 * i + 1];
+            fused += dbg[4 * i + 2];
+            loads += dbg[4 * i + 3];
+            maxcyc = std::max(maxcyc, dbg[4 * i + 1]);
+            maxturns = std::max(maxturns, dbg[4 * i]);
+        }
+        fprintf(stderr, "[ookd] fsm last-run per segment: turns avg %.1f max %llu, fused %.1f, window loads %.1f, "
+                        "memtime ticks avg %.0f max %llu\n",
+                (double)turns / nseg, (unsigned long long)maxturns, (double)fused / nseg, (double)loads / nseg,
+                (double)cyc / nseg, (unsigned long long)maxcyc);
+    }
     final_parity = (iter_next - 1) & 1u;
     stats.fsm_iterations = rounds;
-    HIPCHK(launch_fsm_gather(fp, final_parity, stream));
+    HIPCHK(launch_fsm_gather(fp, stream));
     HIPCHK(hipEventRecord(ev[2], stream));
     return OOKD_OK;
 }
@@ -499,25 +612,21 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                       kMaxStates, kMaxTriggers);
             return nullptr;
         }
+        // the kernel counts elapsed samples in 32 bits (saturating)
+        auto too_long = [](const std::vector<uint64_t> &v) {
+            for (uint64_t x : v) {
+                if (x != ~0ull && x >= (1ull << 31)) return true;
+            }
+            return false;
+        };
+        if (too_long(device->state_kmin) || too_long(device->state_kmax) || too_long(device->state_kto) ||
+            too_long(device->trig_kmin) || too_long(device->trig_kmax)) {
+            set_error("a device duration/timeout exceeds 2^31 samples at this rate: unsupported");
+            return nullptr;
+        }
         std::unique_ptr<FsmTablesDev> t(new FsmTablesDev());
         memset(t.get(), 0, sizeof(FsmTablesDev));
-        t->num_states = (uint32_t)ns;
-        t->max_bits = device->num_bits;
-        t->num_triggers = (uint32_t)nt;
-        for (size_t s = 0; s < ns; ++s) {
-            t->state_kmin[s] = device->state_kmin[s];
-            t->state_kmax[s] = device->state_kmax[s];
-            t->state_kto[s] = device->state_kto[s];
-            t->trig_begin[s] = device->trig_begin[s];
-        }
-        t->trig_begin[ns] = device->trig_begin[ns];
-        for (size_t i = 0; i < nt; ++i) {
-            t->trig_kmin[i] = device->trig_kmin[i];
-            t->trig_kmax[i] = device->trig_kmax[i];
-            t->trig_next[i] = device->trig_next[i];
-            t->trig_cond[i] = device->trig_cond[i];
-            t->trig_action[i] = device->trig_action[i];
-        }
+        fill_fsm_tables(*device, *t);
         if (rx->d_tables.alloc(1) != OOKD_OK) return nullptr;
         if (hipMemcpy(rx->d_tables.p, t.get(), sizeof(FsmTablesDev), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("table upload failed");
@@ -529,13 +638,14 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
 
     // ---- capacities -------------------------------------------------------------------
     const uint64_t spb = cfg->samples_per_buffer;
+    // nominal decimated samples per state machine segment (~2^19 by default;
+    // segment_buffers expresses it in input buffers)
     if (cfg->segment_buffers) {
-        rx->seg_buffers = cfg->segment_buffers;
+        rx->seg_len = std::max<uint64_t>(1, (uint64_t)cfg->segment_buffers * spb / rx->total_decim);
     } else {
-        // ~2^19 decimated samples per segment
-        const uint64_t want = ((1ull << 19) * rx->total_decim + spb - 1) / spb;
-        rx->seg_buffers = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, 1u << 30));
+        rx->seg_len = 1ull << 19;
     }
+    rx->seg_len = std::min<uint64_t>(rx->seg_len, 1ull << 30);   // 32-bit offsets inside a segment
     rx->msg_slots = cfg->message_slots ? cfg->message_slots : 32;
     rx->err_slots = 32;
     uint32_t blocks = 0, segs = 0;
@@ -557,9 +667,11 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rc |= rx->d_halo.alloc(2 * (rx->halo_needed + 4));
     rc |= rx->d_blk_count.alloc(caps * blocks + 1);
     rc |= rx->d_blk_offset.alloc(caps * blocks + 1);
+    rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
     rc |= rx->d_hdr.alloc(1);
     if (rx->have_fsm) {
+        rc |= rx->d_seg_bounds.alloc(caps * (rx->max_segs_per_cap + 1));
         rc |= rx->d_state_in.alloc(nseg);
         rc |= rx->d_state_out.alloc(2 * nseg);
         rc |= rx->d_seg_msgs.alloc(nseg * rx->msg_slots);
@@ -567,6 +679,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rc |= rx->d_seg_msg_count.alloc(nseg);
         rc |= rx->d_seg_err_count.alloc(nseg);
         rc |= rx->d_seg_errs.alloc(nseg * rx->err_slots);
+        if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4);
     }
     if (rc != OOKD_OK) return nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&rx->h_hdr), sizeof(ResultHeader)) != hipSuccess ||
@@ -675,7 +788,7 @@ int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, con
     if (rc != OOKD_OK) return rc;
     if (state_out && rx->have_fsm && rx->run_n_out > 0) {
         const size_t nseg = rx->run_segs_per_cap;
-        HIPCHK(hipMemcpy(state_out, rx->d_state_out.p + (size_t)rx->final_parity * nseg + (nseg - 1),
+        HIPCHK(hipMemcpy(state_out, &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)].st,
                          sizeof(FsmStateDev), hipMemcpyDeviceToHost));
     } else if (state_out) {
         if (state_in) *state_out = *state_in;
@@ -701,7 +814,7 @@ int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in, ookd_fsm_s
     if (rc != OOKD_OK) return rc;
     if (state_out) {
         const size_t nseg = rx->run_segs_per_cap;
-        HIPCHK(hipMemcpy(state_out, rx->d_state_out.p + (size_t)rx->final_parity * nseg + (nseg - 1),
+        HIPCHK(hipMemcpy(state_out, &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)].st,
                          sizeof(FsmStateDev), hipMemcpyDeviceToHost));
     }
     return OOKD_OK;

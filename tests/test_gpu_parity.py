@@ -279,7 +279,7 @@ def test_random_devices_match_oracle(ok, oracle):
         for spb, segb in ((97, 1), (512, 2), (4096, 3)):
             # a random device may emit a message on every sample: one slot per sample
             rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=spb,
-                             segment_buffers=segb, message_slots=spb * segb + 1,
+                             segment_buffers=segb, message_slots=2 * spb * segb + 2,
                              message_capacity=1 << 20, edge_capacity=iq.size)
             got = rx.rx(iq)
             want = oracle.rx(iq, None, 0.1, od, spb, msg_cap=1 << 20)
