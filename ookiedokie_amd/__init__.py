@@ -434,6 +434,10 @@ class Receiver:
     def halo_samples(self) -> int:
         return int(lib().ookd_rx_halo_samples(self._h))
 
+    @staticmethod
+    def state_from_bytes(raw: bytes) -> FsmState:
+        return FsmState.from_buffer_copy(raw)
+
     # -- results --------------------------------------------------------------
     def stats(self) -> dict:
         s = RxStats()

@@ -771,8 +771,10 @@ int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, con
     uint32_t hl = 0;
     if (halo && rx->halo_needed) {
         hl = (uint32_t)rx->halo_needed;
+        // hipMemcpyDefault: the halo may be a host array or a device buffer an
+        // RCCL recv landed in
         HIPCHK(hipMemcpyAsync(rx->d_halo.p, halo + 2 * (halo_samples - hl), (size_t)hl * 4,
-                              hipMemcpyHostToDevice, rx->stream));
+                              hipMemcpyDefault, rx->stream));
     }
     rx->run_caps = 1;
     rx->run_n_valid = num_samples;

@@ -35,6 +35,17 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert built_lib.ookd_api_version() == 1
 
 
+def test_header_is_valid_c99(tmp_path):
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "ookiedokie_amd.h"\n'
+                   'int f(void) { ookd_rx_config c = {0}; ookd_message m; (void)m;\n'
+                   '  return (int)sizeof(ookd_fsm_state) + (int)c.samples_per_buffer + OOKD_FILE_EOF; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only",
+                        "-I", os.path.dirname(ok.HEADER_PATH), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(ok.Message) == 48
     assert C.sizeof(ok.FsmState) == 64
