@@ -150,7 +150,12 @@ enum {
      * order everywhere -- floats bit-identical too, ~half the speed. */
     OOKD_RX_EXACT_FIR = 1u << 0,
     /* Keep the post-filter complexf stream in HBM (parity / --rx-rec). */
-    OOKD_RX_KEEP_FIR = 1u << 1
+    OOKD_RX_KEEP_FIR = 1u << 1,
+    /* State machine: always use the segment/round path.  By default the
+     * state machine runs as a scan of per-edge transition functions and
+     * falls back to this path only when a capture leaves the scan's model
+     * (results are identical either way). */
+    OOKD_RX_FSM_ROUNDS = 1u << 2
 };
 
 typedef struct ookd_rx_config {
@@ -160,7 +165,7 @@ typedef struct ookd_rx_config {
     uint32_t samples_per_buffer;    /* cfg->samples_per_buffer, default 8192  */
     uint64_t max_samples;           /* largest capture (input samples) / run  */
     uint32_t max_captures;          /* captures per batched run (>= 1)        */
-    uint64_t edge_capacity;         /* 0 = default (max_samples/16 + 1M)      */
+    uint64_t edge_capacity;         /* 0 = default (max_samples/32 + 1M)      */
     uint32_t segment_buffers;       /* buffers per FSM segment, 0 = default   */
     uint32_t message_slots;         /* per segment, 0 = default               */
     uint64_t message_capacity;      /* messages per run, 0 = default (65536)  */
@@ -199,6 +204,8 @@ typedef struct ookd_rx_stats {
     uint64_t guard_recomputes;      /* samples redone in exact order          */
     uint32_t fsm_iterations;        /* segment-parallel fix-point rounds      */
     uint32_t num_segments;
+    uint32_t fsm_path;              /* 1 scan, 2 rounds, 3 scan fell back to rounds */
+    uint32_t fsm_fallback_reason;   /* scan's refusal bits (0 = none)         */
     float fir_kernel_ms;            /* HIP-event time of the dominant kernel  */
     float total_device_ms;          /* first kernel start -> last kernel end  */
 } ookd_rx_stats;

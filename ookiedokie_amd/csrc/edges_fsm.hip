@@ -39,10 +39,16 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) {
 // word of level changes: bit b set <=> sample 64*w+b differs from its
 // predecessor (the sample before a capture counts as 0, as record_dig's
 // first line does for sample 0, ookiedokie.c:150-153).
-__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w) {
+// Changes at or beyond n_out do not exist (the words past the capture are
+// zero padding, not samples).
+__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w, uint64_t n_out) {
     const uint64_t cur = words[w];
     const uint64_t prev_top = (w == 0) ? 0ull : (words[w - 1] >> 63);
-    return cur ^ ((cur << 1) | prev_top);
+    const uint64_t e = cur ^ ((cur << 1) | prev_top);
+    const uint64_t base = w * 64;
+    if (base + 64 <= n_out) return e;
+    if (base >= n_out) return 0ull;
+    return e & ((1ull << (n_out - base)) - 1ull);
 }
 
 __global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
     const uint32_t cap = wave / p.blocks_per_cap;
     const uint32_t blk = wave % p.blocks_per_cap;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id());
+    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id(), p.n_out);
     uint32_t c = (uint32_t)__popcll(e);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
     const uint32_t blk = wave % p.blocks_per_cap;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     const uint64_t w = (uint64_t)blk * kBlockWords + lane_id();
-    uint64_t e = change_word(words, w);
+    uint64_t e = change_word(words, w, p.n_out);
     const uint32_t c = (uint32_t)__popcll(e);
     uint32_t inc = c;
 #pragma unroll

@@ -1,0 +1,1263 @@
+// fsm_scan.hip -- the symbol state machine as a parallel scan over edges.
+//
+// The reference runs its state machine sample by sample
+// (src/state_machine.c:421-556).  Between two level changes nothing but
+// always / timeout / msg_complete triggers can fire, and at almost every
+// level change some trigger fires and zeroes the elapsed-time counter, so
+// right after edge i the machine is fully described by a SMALL abstract
+// state
+//        (current state, number of collected bits)      [counter k = 0]
+// plus two "rest of this buffer is being skipped" states (device.c:646) and
+// one "assumption broken" state.  The effect of the samples between edge
+// i-1 and edge i (inclusive) is then a function L_i on that finite set; the
+// machine's trajectory is the prefix composition L_i o ... o L_1 applied to
+// the state after the first edge -- a scan, computed blockwise:
+//
+//   leaf   : per block of edges, build the tables L_i (a handful of tiny
+//            simulations per edge: every state x {few bits, all bits}), and
+//            compose them into one table per block;
+//   blocks : one workgroup per capture walks the block tables from the true
+//            start state;
+//   emit   : per block, walk the true path, then every edge re-simulates its
+//            own span from its now-known incoming state and records what
+//            happened (appended bits, resets, OUTPUT_READY, ERROR);
+//   finish : prefix sums over those records rebuild the payloads (bit t of a
+//            message is the t-th append since the last reset), the message
+//            list, the error list and the outgoing state.
+//
+// Everything is exact or refuses: if the true path ever leaves the abstract
+// model (an edge ignored by a state that is timing something, a span with
+// too many events) the `fallback` word is set and the host reruns the
+// capture with the segment/round path of edges_fsm.hip, which handles
+// anything.  Both paths give identical results (tests run both against the
+// oracle).
+#include "kernels.hpp"
+
+namespace ookd {
+
+namespace {
+
+enum { kCondAlways = 1, kCondPulseStart, kCondPulseEnd, kCondTimeout, kCondMsgComplete };
+enum { kActNone = 1, kActAppend0, kActAppend1, kActOutput };
+enum { kResError = -1, kResNone = 0, kResOutput = 1 };
+
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kSat = 0xfffffffeu;
+constexpr uint32_t kMaxFires = 48;      // trigger firings simulated per span before giving up
+constexpr uint32_t kMaxLeafApps = 30;
+constexpr int kScanThreads = 1024;
+
+// reasons in the fallback word
+enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8 };
+
+// tables in LDS, structure of arrays
+struct LTab {
+    uint32_t tkmin[kMaxTriggers], tkmax[kMaxTriggers], tinfo[kMaxTriggers];
+    uint32_t skmin[kMaxStates], skmax[kMaxStates], skto[kMaxStates], srow[kMaxStates];
+    uint32_t max_bits, S, NB1, D;       // NB1 = max_bits + 2 bit-count values; D = S*NB1 + 3
+    uint32_t spb, decim;
+};
+
+__device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kNone : (uint32_t)v; }
+
+__device__ void load_ltab(LTab &T, const FsmTablesDev *g, uint32_t spb, uint32_t decim) {
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxTriggers; i += blockDim.x) {
+        T.tkmin[i] = clamp32(g->trig_kmin[i]);
+        T.tkmax[i] = clamp32(g->trig_kmax[i]);
+        T.tinfo[i] = g->trig_info[i];
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxStates; i += blockDim.x) {
+        T.skmin[i] = clamp32(g->state_kmin[i]);
+        T.skmax[i] = clamp32(g->state_kmax[i]);
+        T.skto[i] = clamp32(g->state_kto[i]);
+        uint32_t msgc = 0;
+        for (uint32_t t = g->state_tbeg[i]; t < g->state_tend[i] && t < (uint32_t)kMaxTriggers; ++t) {
+            if ((g->trig_info[t] & 0xffu) == kCondMsgComplete) msgc = 1;
+        }
+        T.srow[i] = (g->state_tbeg[i] & 0xffu) | ((g->state_tend[i] & 0xffu) << 8) |
+                    ((g->state_flags[i] & 1u) << 16) | (msgc << 17);
+    }
+    if (threadIdx.x == 0) {
+        T.max_bits = g->max_bits;
+        T.S = g->num_states;
+        T.NB1 = g->max_bits + 2;
+        T.D = g->num_states * (g->max_bits + 2) + 3;
+        T.spb = spb;
+        T.decim = decim;
+    }
+}
+
+// per-lane concrete machine + what happened in the span
+struct PSim {
+    uint32_t cur, nbits, k, prev;
+};
+
+struct Acc {
+    uint32_t napp, appvals, apps_at_reset;
+    uint32_t nout, nerr, fires;
+    uint32_t out_ab0, out_ab1, out_rb0, out_rb1;
+    uint64_t out_pos0, out_pos1, err_pos;
+    bool reset_seen, sensitive, overflow, msgc_seen;
+};
+
+__device__ __forceinline__ void acc_init(Acc &a) {
+    a.napp = a.appvals = a.apps_at_reset = 0;
+    a.nout = a.nerr = a.fires = 0;
+    a.out_ab0 = a.out_ab1 = 0;
+    a.out_rb0 = a.out_rb1 = 0xffu;
+    a.out_pos0 = a.out_pos1 = 0;
+    a.err_pos = 0;
+    a.reset_seen = a.sensitive = a.overflow = a.msgc_seen = false;
+}
+
+__device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
+    const uint64_t s = (uint64_t)k + m;
+    return s > kSat ? kSat : (uint32_t)s;
+}
+
+__device__ __forceinline__ void canon(const LTab &T, PSim &f) {
+    if (T.srow[f.cur] & 0x10000u) f.k = 0;
+}
+
+// state_machine.c:421-519, one evaluation
+__device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
+    const uint32_t s = f.cur;
+    const uint32_t row = T.srow[s];
+    const uint32_t te = (row >> 8) & 0xffu;
+    int fired = -1;
+    uint32_t info = 0;
+    for (uint32_t t = row & 0xffu; t < te; ++t) {
+        if (f.k < T.tkmin[t] || f.k > T.tkmax[t]) continue;
+        info = T.tinfo[t];
+        const uint32_t c = info & 0xffu;
+        bool m;
+        if (c == kCondAlways) {
+            m = true;
+        } else if (c == kCondPulseStart) {
+            m = !f.prev && b;
+        } else if (c == kCondPulseEnd) {
+            m = f.prev && !b;
+        } else if (c == kCondTimeout) {
+            m = f.k >= T.skto[s];
+        } else {
+            m = f.nbits >= T.max_bits;
+            a.msgc_seen = true;
+            // table rows are simulated for a whole class of bit counts; that is
+            // only sound if this test is never reached after an append of the
+            // same span (and before a reset)
+            if (!a.reset_seen && a.napp > 0) a.sensitive = true;
+        }
+        if (m) {
+            fired = (int)t;
+            break;
+        }
+    }
+    if (fired < 0) {
+        f.k = sat_add(f.k, 1);
+        return kResNone;
+    }
+    a.fires++;
+    const uint32_t fc = info & 0xffu, act = (info >> 8) & 0xffu, next = info >> 16;
+    int result = kResNone;
+    bool ok = true;
+    if (fc == kCondPulseStart || fc == kCondPulseEnd) ok = f.k >= T.skmin[s] && f.k <= T.skmax[s];
+    if (ok) {
+        if (act == kActAppend0 || act == kActAppend1) {
+            if (a.napp < kMaxLeafApps) {
+                if (act == kActAppend1) a.appvals |= 1u << a.napp;
+            } else {
+                a.overflow = true;
+            }
+            a.napp++;
+            f.nbits = f.nbits >= kSat ? kSat : f.nbits + 1;
+        } else if (act == kActOutput) {
+            result = kResOutput;
+            const uint32_t rb = a.reset_seen ? a.apps_at_reset : 0xffu;
+            if (a.nout == 0) {
+                a.out_pos0 = pos;
+                a.out_ab0 = a.napp;
+                a.out_rb0 = rb;
+            } else if (a.nout == 1) {
+                a.out_pos1 = pos;
+                a.out_ab1 = a.napp;
+                a.out_rb1 = rb;
+            } else {
+                a.overflow = true;
+            }
+            a.nout++;
+        }
+        f.cur = next;
+    } else {
+        result = kResError;
+        f.cur = 0;
+        if (a.nerr == 0) a.err_pos = pos;
+        else a.overflow = true;                     // one error per span is all the record holds
+        a.nerr++;
+    }
+    f.k = 0;
+    return result;
+}
+
+// state_machine.c:521-539
+__device__ __forceinline__ int p_step(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
+    if (f.cur == 0) {
+        f.nbits = 0;
+        a.reset_seen = true;
+        a.apps_at_reset = a.napp;
+        const int r = p_eval(T, f, a, b, pos);
+        if (r != kResNone) return r;
+    }
+    return p_eval(T, f, a, b, pos);
+}
+
+// evaluations until an always / timeout / msg_complete trigger fires while
+// the level stays constant (kNone = never)
+__device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &f, Acc &a) {
+    const uint32_t s = f.cur;
+    const uint32_t row = T.srow[s];
+    const uint32_t te = (row >> 8) & 0xffu;
+    const uint32_t kto = T.skto[s];
+    uint32_t best = kNone;
+    for (uint32_t t = row & 0xffu; t < te; ++t) {
+        const uint32_t c = T.tinfo[t] & 0xffu;
+        uint32_t lo = T.tkmin[t];
+        if (c == kCondTimeout) {
+            if (kto == kNone) continue;
+            lo = lo > kto ? lo : kto;
+        } else if (c == kCondMsgComplete) {
+            a.msgc_seen = true;
+            if (!a.reset_seen && a.napp > 0) a.sensitive = true;
+            if (f.nbits < T.max_bits) continue;
+        } else if (c != kCondAlways) {
+            continue;
+        }
+        const uint32_t first = f.k > lo ? f.k : lo;
+        if (first > T.tkmax[t] || first > kSat) continue;
+        const uint32_t w = first - f.k;
+        best = w < best ? w : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ uint64_t next_buffer_start(const LTab &T, uint64_t pos) {
+    const uint64_t in_idx = (uint64_t)T.decim * (pos + 1) - 1;
+    const uint64_t buf = in_idx / T.spb;
+    const uint64_t nb = ((buf + 1) * (uint64_t)T.spb) / T.decim;
+    return nb > pos ? nb : pos + 1;
+}
+
+// Runs `n` samples of constant level L starting at absolute position pos0,
+// then (has_edge) one sample of level !L.  Returns false when the span ends
+// inside a skipped rest-of-buffer (f.prev = the level of the error sample).
+__device__ __forceinline__ bool sim_span(const LTab &T, PSim &f, Acc &a, uint64_t pos0, uint32_t L, uint64_t n, bool has_edge) {
+    uint64_t pos = pos0;
+    const uint64_t end_const = pos0 + n;
+    const uint64_t last = end_const + (has_edge ? 1 : 0);
+    while (pos < last) {
+        const uint32_t b = pos < end_const ? L : (L ^ 1u);
+        if (b == f.prev && pos < end_const) {
+            const uint64_t room = end_const - pos;
+            const uint32_t q = p_quiet(T, f, a);
+            uint64_t m;
+            if (f.cur == 0) {
+                m = q == kNone ? room : (uint64_t)(q >> 1);    // reset evaluates twice per sample
+                if (m > room) m = room;
+                f.k = sat_add(f.k, 2 * m);
+            } else {
+                m = q == kNone ? room : (uint64_t)q;
+                if (m > room) m = room;
+                f.k = sat_add(f.k, m);
+            }
+            if (m > 0) {
+                canon(T, f);
+                pos += m;
+                continue;
+            }
+        }
+        if (a.fires > kMaxFires) {
+            a.overflow = true;
+            return true;
+        }
+        const int r = p_step(T, f, a, b, pos);
+        f.prev = b;
+        canon(T, f);
+        if (r == kResError) {
+            if (pos + 1 >= last) return false;      // error on the span's last sample: skip starts beyond it
+            const uint64_t nb = next_buffer_start(T, pos);
+            if (nb >= last) return false;           // still skipping when the span ends
+            pos = nb;                               // resume inside this span: reset, k = 0
+            continue;
+        }
+        pos += 1;
+    }
+    return true;
+}
+
+struct Span {                   // the samples a leaf covers
+    uint64_t pos0, n;
+    uint32_t L;
+    bool has_edge;
+};
+
+// leaf i (1 <= i < ne): samples e[i-1]+1 .. e[i]
+__device__ __forceinline__ Span span_of(const uint64_t *edges, uint64_t i) {
+    Span s;
+    s.pos0 = edges[i - 1] + 1;
+    s.n = edges[i] - edges[i - 1] - 1;
+    s.L = (uint32_t)(i & 1ull);         // level after edge i-1
+    s.has_edge = true;
+    return s;
+}
+
+// abstract codes:  cur * NB1 + nb | skip(prev 0/1) | poison
+__device__ __forceinline__ uint32_t code_skip(const LTab &T, uint32_t prev) { return T.S * T.NB1 + prev; }
+__device__ __forceinline__ uint32_t code_poison(const LTab &T) { return T.S * T.NB1 + 2; }
+
+// Concrete run of span sp from abstract state `code`; `resume` = first sample
+// after the buffer of the edge that precedes the span (where a skip state
+// starts feeding samples again).  Returns alive (false = ends inside a
+// skip); f is the machine at the end.  Must not be called with the poison code.
+__device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f, Acc &a) {
+    const uint32_t nstates = T.S * T.NB1;
+    acc_init(a);
+    if (code >= nstates) {
+        f.cur = 0;
+        f.nbits = 0;
+        f.k = 0;
+        f.prev = code - nstates;
+        const uint64_t end_const = sp.pos0 + sp.n;
+        const uint64_t last = end_const + (sp.has_edge ? 1 : 0);
+        if (resume >= last) return false;
+        if (resume >= end_const) return sim_span(T, f, a, resume, sp.L, 0, sp.has_edge);
+        return sim_span(T, f, a, resume, sp.L, end_const - resume, sp.has_edge);
+    }
+    f.cur = code / T.NB1;
+    f.nbits = code % T.NB1;
+    f.k = 0;
+    f.prev = sp.L;
+    return sim_span(T, f, a, sp.pos0, sp.L, sp.n, sp.has_edge);
+}
+
+__device__ __forceinline__ uint32_t encode_post(const LTab &T, const PSim &f, const Acc &a, bool alive) {
+    if (a.overflow) return code_poison(T);
+    if (!alive) return code_skip(T, f.prev);
+    if (f.k != 0 && !(T.srow[f.cur] & 0x10000u)) return code_poison(T);   // counter not zeroed: not representable
+    return f.cur * T.NB1 + (f.nbits >= T.NB1 ? T.NB1 - 1 : f.nbits);
+}
+
+}  // namespace
+
+struct ScanParams {
+    FsmParams f;
+    uint16_t *block_tab;
+    uint16_t *block_in;
+    uint32_t *cap_block_off;
+    LeafEvDev *events;
+    uint8_t *app_vals;
+    uint64_t app_capacity;
+    uint64_t *errs;
+    uint64_t err_capacity;
+    FsmStateDev first;
+    int have_first;
+    SegState *final_state;
+    uint32_t *fallback;
+    uint32_t total_blocks_cap;
+    uint32_t leaf_block;        // leaves per block (<= 256)
+    uint32_t *fin_off;          // [captures + 1] prefix of finish-block counts
+    uint4 *fsum;                // [finish blocks] appends, outputs, errors, last epoch start + 1
+    uint4 *fbase;               // [finish blocks] exclusive prefixes + epoch entering the block
+    unsigned long long *cap_base;   // [captures][2] message / error slot bases
+    uint32_t fin_blocks_cap;
+    uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
+    uint32_t Dp;                // block table row pitch (D rounded up to 8)
+};
+
+namespace {
+
+__device__ __forceinline__ uint64_t cap_edges(const FsmParams &p, uint32_t cap, uint64_t &e0) {
+    const uint32_t blk0 = cap * p.blocks_per_cap;
+    e0 = p.blk_offset[blk0];
+    return (uint64_t)p.blk_offset[blk0 + p.blocks_per_cap] - e0;
+}
+
+
+// position p of a block -> leaf index, even leaves first then odd ones
+__device__ __forceinline__ uint32_t parity_order(uint32_t p, uint32_t count) {
+    const uint32_t evens = (count + 1) >> 1;
+    return p < evens ? 2 * p : (p < count ? 2 * (p - evens) + 1 : count);
+}
+
+// Builds the transition tables of leaves [first, first+count) into LDS:
+// tab[l * D + d].
+// Phase A of a block's tables: per leaf, the packed results of the class
+// simulations, res[l][2S+2] (two per state: "few bits" nb = 0 standing for
+// every nb < max_bits, "all bits" nb = max_bits standing for nb >= max_bits;
+// then the two skip states).  Lanes of a wave share the start state and take
+// leaves of equal level (even leaves first, then odd), so they follow nearly
+// the same path.
+__shared__ uint32_t s_nuniq;
+
+__device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
+                           uint64_t *resume, uint16_t *rep /* [count] */, uint16_t *uniq /* [count + 1] */) {
+    const uint32_t S = T.S, NB1 = T.NB1;
+    const uint32_t nsim = 2 * S + 2;
+    // one 64-bit division per leaf instead of one per simulation
+    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) resume[l] = next_buffer_start(T, edges[first + l - 1]);
+    // From a normal state the outcome of a span depends only on its level and
+    // length, not on where it lies: simulate each distinct (level, length) of the
+    // block once.  rep[l] = first leaf of the block with the same key.
+    uint32_t *gap = res;                        // scratch: res is rewritten below
+    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+        const uint64_t n = edges[first + l] - edges[first + l - 1];
+        gap[l] = n > 0xfffffffeull ? 0xffffffffu - l : (uint32_t)n;     // giant gaps never match
+    }
+    __syncthreads();
+    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+        const uint32_t n = gap[l];
+        uint32_t r = l;
+        for (uint32_t m = l & 1u; m < l; m += 2) {          // leaves of equal parity share the level
+            if (gap[m] == n) {
+                r = m;
+                break;
+            }
+        }
+        rep[l] = (uint16_t)r;
+    }
+    __syncthreads();
+    // list of representatives, even leaves first then odd ones (lanes of a wave
+    // then share the level); position = rank in that order
+    if (threadIdx.x == 0) uniq[0] = 0;
+    __syncthreads();
+    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+        if (rep[l] != l) continue;
+        uint32_t rank = 0;
+        for (uint32_t m = 0; m < count; ++m) {
+            if (rep[m] != m) continue;
+            const bool before = ((m & 1u) < (l & 1u)) || (((m & 1u) == (l & 1u)) && m < l);
+            rank += before ? 1u : 0u;
+        }
+        uniq[1 + rank] = (uint16_t)l;
+        atomicAdd(reinterpret_cast<uint32_t *>(&s_nuniq), 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uniq[0] = (uint16_t)s_nuniq;
+        s_nuniq = 0;
+    }
+    __syncthreads();
+    const uint32_t nu = uniq[0];
+    const uint32_t upad = (nu + 63u) & ~63u, cpad = (count + 63u) & ~63u;
+    const uint32_t ntask = upad * S + cpad * 2;
+    for (uint32_t task = threadIdx.x; task < ntask; task += blockDim.x) {
+        PSim f;
+        Acc a;
+        if (task >= upad * S) {
+            // skip states: position dependent, every leaf
+            const uint32_t t2 = task - upad * S;
+            const uint32_t k = t2 / cpad, lp = t2 - k * cpad;
+            const uint32_t l = parity_order(lp, count);
+            if (l >= count) continue;
+            const bool alive = run_leaf(T, code_skip(T, k), span_of(edges, first + l), resume[l], f, a);
+            res[l * nsim + 2 * S + k] = encode_post(T, f, a, alive) | 0x80000000u;     // absolute
+            continue;
+        }
+        const uint32_t k = task / upad, up = task - k * upad;
+        if (up >= nu) continue;
+        const uint32_t l = uniq[1 + up];
+        const Span sp = span_of(edges, first + l);
+        const uint64_t pe = resume[l];
+        for (uint32_t cls = 0; cls < 2; ++cls) {
+            const uint32_t nb0 = cls ? T.max_bits : 0u;
+            const bool alive = run_leaf(T, k * NB1 + nb0, sp, pe, f, a);
+            const uint32_t out = encode_post(T, f, a, alive);
+            uint32_t packed;
+            if (out >= S * NB1) {
+                packed = out | 0x80000000u;                     // skip / poison
+            } else if (a.sensitive) {
+                packed = 0x40000000u;                           // row needs one simulation per bit count
+            } else if (a.reset_seen) {
+                packed = out | 0x80000000u;                     // bit count restarted inside the span
+            } else {
+                const uint32_t ocur = out / NB1;
+                const uint32_t nbo = out - ocur * NB1;
+                const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
+                packed = ocur | (delta << 8) | 0x20000000u;     // relative: nb + delta (saturating)
+            }
+            res[l * nsim + 2 * k + cls] = packed;
+            if (cls == 0 && !a.msgc_seen && !a.overflow) {
+                // no dependence on the bit count at all: both classes share the run
+                res[l * nsim + 2 * k + 1] = packed;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // the other leaves take their representative's rows
+    for (uint32_t e = threadIdx.x; e < count * 2 * S; e += blockDim.x) {
+        const uint32_t l = e / (2 * S), c = e - l * (2 * S);
+        const uint32_t r = rep[l];
+        if (r != l) res[l * nsim + c] = res[r * nsim + c];
+    }
+    __syncthreads();
+}
+
+// Phase B: expand the packed results into the tables tab[l * D + d].  Work
+// item = (leaf, state row); a lane fills the row's NB1 entries.
+__device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint16_t *tab,
+                             const uint32_t *res, const uint64_t *resume) {
+    const uint32_t S = T.S, NB1 = T.NB1, D = T.D;
+    const uint32_t nsim = 2 * S + 2;
+    const uint32_t nrow = count * (S + 1);
+    for (uint32_t item = threadIdx.x; item < nrow; item += blockDim.x) {
+        const uint32_t l = item / (S + 1), cur = item - l * (S + 1);
+        uint16_t *row = tab + l * D;
+        const uint32_t *r = res + l * nsim;
+        if (cur == S) {
+            row[S * NB1] = (uint16_t)(r[2 * S] & 0xffffu);
+            row[S * NB1 + 1] = (uint16_t)(r[2 * S + 1] & 0xffffu);
+            row[S * NB1 + 2] = (uint16_t)(S * NB1 + 2);         // poison stays poison
+            continue;
+        }
+        const uint32_t pk_lo = r[2 * cur], pk_hi = r[2 * cur + 1];
+        for (uint32_t nb = 0; nb < NB1; ++nb) {
+            const uint32_t pk = nb >= T.max_bits ? pk_hi : pk_lo;
+            uint32_t out;
+            if (pk & 0x80000000u) {
+                out = pk & 0xffffu;
+            } else if (pk & 0x20000000u) {
+                uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+                if (nbo >= NB1) nbo = NB1 - 1;
+                out = (pk & 0xffu) * NB1 + nbo;
+            } else {
+                // exact per-count simulation (rare)
+                PSim f;
+                Acc a;
+                const uint64_t i = first + l;
+                const bool alive = run_leaf(T, cur * NB1 + nb, span_of(edges, i), resume[l], f, a);
+                out = encode_post(T, f, a, alive);
+            }
+            row[cur * NB1 + nb] = (uint16_t)out;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void locate_block(const ScanParams &sp, uint32_t gb, uint32_t &cap, uint32_t &lb) {
+    uint32_t lo = 0, hi = sp.f.num_captures;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sp.cap_block_off[mid] <= gb) lo = mid;
+        else hi = mid;
+    }
+    cap = lo;
+    lb = gb - sp.cap_block_off[lo];
+}
+
+// A capture's first span (samples 0 .. first edge; the whole capture when it
+// has no edge) from the concrete incoming state.
+__device__ __forceinline__ bool first_leaf(const LTab &T, const ScanParams &sp, const uint64_t *edges, uint64_t ne, PSim &f,
+                           Acc &a) {
+    f.cur = sp.have_first ? sp.first.cur : 0u;
+    f.nbits = sp.have_first ? sp.first.nbits : 0u;
+    f.prev = sp.have_first ? sp.first.prev : 0u;
+    const uint64_t k64 = sp.have_first ? sp.first.k : 0ull;
+    f.k = k64 > kSat ? kSat : (uint32_t)k64;
+    acc_init(a);
+    const uint64_t n = ne ? edges[0] : sp.f.n_out;
+    return sim_span(T, f, a, 0, 0u, n, ne != 0);
+}
+
+__device__ __forceinline__ void write_event(LeafEvDev &ev, const Acc &a, const PSim &f, bool alive) {
+    ev.napp = (uint8_t)(a.napp > 255u ? 255u : a.napp);
+    ev.nout = (uint8_t)(a.nout > 255u ? 255u : a.nout);
+    ev.nerr = (uint8_t)(a.nerr > 255u ? 255u : a.nerr);
+    ev.flags = (uint8_t)((a.reset_seen ? 1u : 0u) | (alive ? 0u : 4u));
+    ev.apps_at_reset = (uint8_t)a.apps_at_reset;
+    ev.out_ab[0] = (uint8_t)a.out_ab0;
+    ev.out_ab[1] = (uint8_t)a.out_ab1;
+    ev.out_rb[0] = (uint8_t)a.out_rb0;
+    ev.out_rb[1] = (uint8_t)a.out_rb1;
+    ev.end_cur = (uint8_t)f.cur;
+    ev.end_prev = (uint8_t)f.prev;
+    ev.pad = 0;
+    ev.appvals = a.appvals;
+    ev.end_k = f.k;
+    ev.out_pos[0] = a.out_pos0;
+    ev.out_pos[1] = a.out_pos1;
+    ev.err_pos = a.err_pos;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+constexpr int kSimThreads = 256;        // leaf / emit kernels (register-heavy simulations)
+constexpr int kChunk = 16;              // leaves per composition chunk inside a block
+constexpr int kFinBlock = 1024;         // leaves per finish block
+
+extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+
+struct BlockLds {
+    uint16_t *tab;      // [LB][D]   leaf tables
+    uint16_t *ctab;     // [LB/16][D] chunk tables
+    uint32_t *res;      // [LB][2S+2]
+};
+
+__device__ __forceinline__ BlockLds carve(uint32_t LB, uint32_t D) {
+    BlockLds b;
+    size_t off = 0;
+    b.tab = reinterpret_cast<uint16_t *>(scan_smem + off);
+    off += ((size_t)LB * D * 2 + 15) & ~(size_t)15;
+    b.ctab = reinterpret_cast<uint16_t *>(scan_smem + off);
+    off += ((size_t)((LB + kChunk - 1) / kChunk) * D * 2 + 15) & ~(size_t)15;
+    b.res = reinterpret_cast<uint32_t *>(scan_smem + off);
+    return b;
+}
+
+static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S) {
+    size_t off = ((size_t)LB * D * 2 + 15) & ~(size_t)15;
+    off += ((size_t)((LB + kChunk - 1) / kChunk) * D * 2 + 15) & ~(size_t)15;
+    off += (size_t)LB * (2 * S + 2) * 4;
+    return off;
+}
+
+// chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
+__device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t count) {
+    const uint32_t nch = (count + kChunk - 1) / kChunk;
+    for (uint32_t item = threadIdx.x; item < nch * D; item += blockDim.x) {
+        const uint32_t c = item / D, d = item - c * D;
+        const uint32_t l1 = min((c + 1) * kChunk, count);
+        uint32_t s = d;
+        for (uint32_t l = c * kChunk; l < l1; ++l) s = b.tab[l * D + s];
+        b.ctab[c * D + d] = (uint16_t)s;
+    }
+    __syncthreads();
+}
+
+// prefix of per-capture block counts: scan blocks (regular leaves) and finish
+// blocks (all leaves); one workgroup
+__global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp) {
+    __shared__ uint32_t part[kScanThreads], part2[kScanThreads];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nc = sp.f.num_captures;
+    const uint32_t chunk = (nc + kScanThreads - 1) / kScanThreads;
+    const uint32_t lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
+    uint32_t sum = 0, sum2 = 0;
+    for (uint32_t c = lo; c < hi; ++c) {
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, c, e0);
+        const uint64_t regular = ne > 1 ? ne - 1 : 0;
+        sum += (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        sum2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
+    }
+    part[tid] = sum;
+    part2[tid] = sum2;
+    __syncthreads();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        const uint32_t v2 = tid >= d ? part2[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        part2[tid] += v2;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum, run2 = part2[tid] - sum2;
+    for (uint32_t c = lo; c < hi; ++c) {
+        sp.cap_block_off[c] = run;
+        sp.fin_off[c] = run2;
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, c, e0);
+        const uint64_t regular = ne > 1 ? ne - 1 : 0;
+        run += (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        run2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
+    }
+    if (tid == kScanThreads - 1) {
+        sp.cap_block_off[nc] = part[tid];
+        sp.fin_off[nc] = part2[tid];
+        if (part[tid] > sp.total_blocks_cap || part2[tid] > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
+    }
+}
+
+__global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
+    __shared__ LTab T;
+    __shared__ uint64_t s_resume[256];
+    __shared__ uint16_t s_rep[256], s_uniq[258];
+    if (threadIdx.x == 0) s_nuniq = 0;
+    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
+    __syncthreads();
+    if (*sp.fallback) return;
+    const uint32_t D = T.D, LB = sp.leaf_block;
+    const BlockLds b = carve(LB, D);
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    for (uint32_t gb = blockIdx.x; gb < total; gb += gridDim.x) {
+        uint32_t cap, lb;
+        locate_block(sp, gb, cap, lb);
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t *edges = sp.f.edges + e0;
+        const uint64_t first = 1 + (uint64_t)lb * LB;
+        const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+        const uint64_t st0 = __builtin_amdgcn_s_memtime();
+        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq);
+        const uint64_t st1 = __builtin_amdgcn_s_memtime();
+        {
+            // keep the packed results: the emit kernel rebuilds the tables from them
+            const uint32_t nsim = 2 * T.S + 2;
+            uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
+            for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
+        }
+        block_expand(T, edges, first, count, b.tab, b.res, s_resume);
+        const uint64_t st2 = __builtin_amdgcn_s_memtime();
+        compose_chunks(b, D, count);
+        const uint64_t st3 = __builtin_amdgcn_s_memtime();
+        if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
+            sp.f.debug[4 * gb + 0] = st1 - st0;
+            sp.f.debug[4 * gb + 1] = st2 - st1;
+            sp.f.debug[4 * gb + 2] = st3 - st2;
+            sp.f.debug[4 * gb + 3] = s_uniq[0];
+        }
+        // the block's table: every abstract state walks the chunk tables
+        const uint32_t nch = (count + kChunk - 1) / kChunk;
+        for (uint32_t d = threadIdx.x; d < D; d += blockDim.x) {
+            uint32_t s = d;
+            for (uint32_t c = 0; c < nch; ++c) s = b.ctab[c * D + s];
+            sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per capture walks its block tables from the true start state.
+// Two levels so the walk is short: groups of 16 block tables are composed in
+// parallel, one lane walks the group tables, then one lane per group walks
+// its 16 blocks.
+constexpr int kGroup = 16;              // block tables per group
+constexpr int kStageBlocks = 128;       // block tables staged in LDS at a time
+constexpr int kSuperGroups = 64;        // groups per sequential super-chunk
+
+__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(ScanParams sp) {
+    __shared__ LTab T;
+    __shared__ uint32_t x;
+    __shared__ uint16_t gin[kSuperGroups];
+    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
+    __syncthreads();
+    if (*sp.fallback) return;
+    const uint32_t D = T.D;
+    const uint32_t Dp = sp.Dp;                                              // row pitch, multiple of 8 entries
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);              // [kStageBlocks][Dp]
+    uint16_t *gtab = stage + (size_t)kStageBlocks * Dp;                     // [kSuperGroups][D]
+    for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t *edges = sp.f.edges + e0;
+        const uint32_t b0 = sp.cap_block_off[cap], b1 = sp.cap_block_off[cap + 1];
+        if (threadIdx.x == 0) {
+            PSim f;
+            Acc a;
+            const bool alive = first_leaf(T, sp, edges, ne, f, a);
+            x = encode_post(T, f, a, alive);
+        }
+        __syncthreads();
+        for (uint32_t sc = b0; sc < b1; sc += kSuperGroups * kGroup) {
+            const uint32_t sc_end = min(sc + (uint32_t)(kSuperGroups * kGroup), b1);
+            const uint32_t ng = (sc_end - sc + kGroup - 1) / kGroup;
+            // pass 1: group tables
+            for (uint32_t cb = sc; cb < sc_end; cb += kStageBlocks) {
+                const uint32_t nb = min((uint32_t)kStageBlocks, sc_end - cb);
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)cb * Dp);
+                    uint4 *dst = reinterpret_cast<uint4 *>(stage);
+                    for (uint32_t i = threadIdx.x; i < nb * (Dp / 8); i += blockDim.x) dst[i] = src[i];
+                }
+                __syncthreads();
+                const uint32_t ngl = (nb + kGroup - 1) / kGroup;
+                for (uint32_t item = threadIdx.x; item < ngl * D; item += blockDim.x) {
+                    const uint32_t g = item / D, d = item - g * D;
+                    const uint32_t j1 = min((g + 1) * kGroup, nb);
+                    uint32_t s = d;
+                    for (uint32_t j = g * kGroup; j < j1; ++j) s = stage[j * Dp + s];
+                    gtab[((cb - sc) / kGroup + g) * D + d] = (uint16_t)s;
+                }
+                __syncthreads();
+            }
+            // walk the groups
+            if (threadIdx.x == 0) {
+                uint32_t s = x;
+                for (uint32_t g = 0; g < ng; ++g) {
+                    gin[g] = (uint16_t)s;
+                    s = gtab[g * D + s];
+                }
+                x = s;
+            }
+            __syncthreads();
+            // pass 2: state entering every block
+            for (uint32_t cb = sc; cb < sc_end; cb += kStageBlocks) {
+                const uint32_t nb = min((uint32_t)kStageBlocks, sc_end - cb);
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)cb * Dp);
+                    uint4 *dst = reinterpret_cast<uint4 *>(stage);
+                    for (uint32_t i = threadIdx.x; i < nb * (Dp / 8); i += blockDim.x) dst[i] = src[i];
+                }
+                __syncthreads();
+                const uint32_t ngl = (nb + kGroup - 1) / kGroup;
+                if (threadIdx.x < ngl) {
+                    const uint32_t g = threadIdx.x;
+                    const uint32_t j1 = min((g + 1) * kGroup, nb);
+                    uint32_t s = gin[(cb - sc) / kGroup + g];
+                    for (uint32_t j = g * kGroup; j < j1; ++j) {
+                        sp.block_in[cb + j] = (uint16_t)s;
+                        s = stage[j * Dp + s];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
+__global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
+    __shared__ LTab T;
+    __shared__ uint64_t s_resume[256];
+    __shared__ uint16_t pre[257];
+    __shared__ uint16_t cin[32];
+    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
+    __syncthreads();
+    if (*sp.fallback) return;
+    const uint32_t D = T.D, LB = sp.leaf_block;
+    const BlockLds b = carve(LB, D);
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    // work items: every block, then one "ends" item per capture (first span + tail)
+    for (uint32_t w = blockIdx.x; w < total + sp.f.num_captures; w += gridDim.x) {
+        if (w < total) {
+            uint32_t cap, lb;
+            locate_block(sp, w, cap, lb);
+            uint64_t e0;
+            const uint64_t ne = cap_edges(sp.f, cap, e0);
+            const uint64_t *edges = sp.f.edges + e0;
+            LeafEvDev *events = sp.events + e0 + cap;
+            const uint64_t first = 1 + (uint64_t)lb * LB;
+            const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+            {
+                const uint32_t nsim = 2 * T.S + 2;
+                const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
+                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) b.res[i] = src[i];
+                for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+                    s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
+                }
+            }
+            __syncthreads();
+            block_expand(T, edges, first, count, b.tab, b.res, s_resume);
+            compose_chunks(b, D, count);
+            const uint32_t nch = (count + kChunk - 1) / kChunk;
+            if (threadIdx.x == 0) {             // state entering each chunk
+                uint32_t s = sp.block_in[w];
+                for (uint32_t c = 0; c < nch; ++c) {
+                    cin[c] = (uint16_t)s;
+                    s = b.ctab[c * D + s];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < nch) {            // state entering each leaf
+                const uint32_t c = threadIdx.x;
+                const uint32_t l1 = min((c + 1) * kChunk, count);
+                uint32_t s = cin[c];
+                for (uint32_t l = c * kChunk; l < l1; ++l) {
+                    pre[l] = (uint16_t)s;
+                    s = b.tab[l * D + s];
+                }
+            }
+            __syncthreads();
+            for (uint32_t lp = threadIdx.x; lp < count; lp += blockDim.x) {
+                const uint32_t l = parity_order(lp, count);
+                const uint64_t i = first + l;
+                const uint32_t in = pre[l];
+                PSim f;
+                Acc a;
+                bool alive = true;
+                if (in == code_poison(T)) {
+                    atomicOr(sp.fallback, (uint32_t)kFbPoison);
+                    acc_init(a);
+                    f.cur = f.nbits = f.k = f.prev = 0;
+                } else {
+                    alive = run_leaf(T, in, span_of(edges, i), s_resume[l], f, a);
+                    if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                }
+                write_event(events[i], a, f, alive);
+            }
+            __syncthreads();
+        } else {
+            const uint32_t cap = w - total;
+            uint64_t e0;
+            const uint64_t ne = cap_edges(sp.f, cap, e0);
+            const uint64_t *edges = sp.f.edges + e0;
+            LeafEvDev *events = sp.events + e0 + cap;
+            if (threadIdx.x == 0) {
+                // first span, from the concrete incoming state
+                PSim f;
+                Acc a;
+                const bool alive = first_leaf(T, sp, edges, ne, f, a);
+                if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                write_event(events[0], a, f, alive);
+            }
+            if (threadIdx.x == 64 && ne > 0) {
+                // tail: the samples after the last edge
+                uint32_t in;
+                if (ne == 1) {
+                    PSim f0;
+                    Acc a0;
+                    const bool al0 = first_leaf(T, sp, edges, ne, f0, a0);
+                    in = encode_post(T, f0, a0, al0);
+                } else {
+                    const uint32_t lastb = sp.cap_block_off[cap + 1] - 1;
+                    in = sp.block_tab[(size_t)lastb * sp.Dp + sp.block_in[lastb]];
+                }
+                const uint64_t pos0 = edges[ne - 1] + 1;
+                Span tail;
+                tail.pos0 = pos0;
+                tail.n = sp.f.n_out > pos0 ? sp.f.n_out - pos0 : 0;
+                tail.L = (uint32_t)(ne & 1ull);
+                tail.has_edge = false;
+                PSim f;
+                Acc a;
+                bool alive = true;
+                if (in == code_poison(T)) {
+                    atomicOr(sp.fallback, (uint32_t)kFbPoison);
+                    acc_init(a);
+                    f.cur = f.nbits = f.k = f.prev = 0;
+                } else {
+                    alive = run_leaf(T, in, tail, next_buffer_start(T, edges[ne - 1]), f, a);
+                    if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                }
+                write_event(events[ne], a, f, alive);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- finish: records -> payloads / messages / errors / outgoing state --------------
+//
+// Appends get ordinals in time order (bits the machine already held when the
+// capture / shard began count as ordinals 0 .. nb0-1).  `epoch` = ordinal of
+// the first append after the last pass through reset: the payload at any time
+// is appends epoch .. (epoch + max_bits), bit t = append epoch + t
+// (state_machine.c:365-385: stored while num_bits <= max_bits).
+
+__device__ __forceinline__ void locate_fin(const ScanParams &sp, uint32_t gfb, uint32_t &cap, uint32_t &fb) {
+    uint32_t lo = 0, hi = sp.f.num_captures;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sp.fin_off[mid] <= gfb) lo = mid;
+        else hi = mid;
+    }
+    cap = lo;
+    fb = gfb - sp.fin_off[lo];
+}
+
+// workgroup inclusive scans over 1024 lanes: sums of (a, o, e) and max of r
+__device__ void wg_scan4(uint32_t &a, uint32_t &o, uint32_t &e, uint32_t &r, uint32_t (*sh)[kFinBlock]) {
+    const uint32_t tid = threadIdx.x;
+    sh[0][tid] = a;
+    sh[1][tid] = o;
+    sh[2][tid] = e;
+    sh[3][tid] = r;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)kFinBlock; d <<= 1) {
+        uint32_t va = 0, vo = 0, ve = 0, vr = 0;
+        if (tid >= d) {
+            va = sh[0][tid - d];
+            vo = sh[1][tid - d];
+            ve = sh[2][tid - d];
+            vr = sh[3][tid - d];
+        }
+        __syncthreads();
+        sh[0][tid] += va;
+        sh[1][tid] += vo;
+        sh[2][tid] += ve;
+        sh[3][tid] = max(sh[3][tid], vr);
+        __syncthreads();
+    }
+    a = sh[0][tid];
+    o = sh[1][tid];
+    e = sh[2][tid];
+    r = sh[3][tid];
+}
+
+struct FinLeaf {                // one lane = one leaf of a finish block
+    LeafEvDev ev;
+    bool have;
+    uint32_t a_in, o_in, e_in;  // block-local exclusive prefixes
+    uint32_t r_in;              // block-local (ordinal of last epoch start before this leaf) + 1, 0 = none
+    uint32_t a_tot, o_tot, e_tot, r_tot;
+};
+
+__device__ void fin_block_scan(const ScanParams &sp, uint32_t cap, uint32_t fb, FinLeaf &L,
+                               uint32_t (*sh)[kFinBlock]) {
+    uint64_t e0;
+    const uint64_t ne = cap_edges(sp.f, cap, e0);
+    const uint64_t i = (uint64_t)fb * kFinBlock + threadIdx.x;
+    L.have = i <= ne;
+    if (L.have) L.ev = sp.events[e0 + cap + i];
+    uint32_t a = L.have ? L.ev.napp : 0u, o = L.have ? L.ev.nout : 0u, e = L.have ? L.ev.nerr : 0u;
+    const uint32_t na = a, no = o, nerr = e;
+    uint32_t r = 0;
+    // first get the append prefix, then the epoch-start candidates need it
+    uint32_t dummy = 0;
+    wg_scan4(a, o, e, dummy, sh);
+    L.a_in = a - na;
+    L.o_in = o - no;
+    L.e_in = e - nerr;
+    L.a_tot = sh[0][kFinBlock - 1];
+    L.o_tot = sh[1][kFinBlock - 1];
+    L.e_tot = sh[2][kFinBlock - 1];
+    __syncthreads();
+    r = (L.have && (L.ev.flags & 1u)) ? L.a_in + L.ev.apps_at_reset + 1 : 0u;
+    uint32_t z0 = 0, z1 = 0, z2 = 0;
+    const uint32_t mine = r;
+    wg_scan4(z0, z1, z2, r, sh);
+    L.r_tot = sh[3][kFinBlock - 1];
+    // exclusive: the value of the lane before
+    __syncthreads();
+    L.r_in = threadIdx.x ? sh[3][threadIdx.x - 1] : 0u;
+    (void)mine;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kFinBlock) void fin_sum_kernel(ScanParams sp) {
+    __shared__ uint32_t sh[4][kFinBlock];
+    if (*sp.fallback) return;
+    const uint32_t total = sp.fin_off[sp.f.num_captures];
+    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+        uint32_t cap, fb;
+        locate_fin(sp, g, cap, fb);
+        FinLeaf L;
+        fin_block_scan(sp, cap, fb, L, sh);
+        if (threadIdx.x == 0) sp.fsum[g] = make_uint4(L.a_tot, L.o_tot, L.e_tot, L.r_tot);
+    }
+}
+
+// per capture: exclusive scan over its finish blocks; message / error slots
+__global__ __launch_bounds__(kScanThreads) void fin_scan_kernel(ScanParams sp) {
+    __shared__ unsigned long long base_msg, base_err;
+    if (*sp.fallback) return;
+    const uint32_t max_bits = sp.f.tables->max_bits;
+    for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
+        const uint32_t f0 = sp.fin_off[cap], f1 = sp.fin_off[cap + 1];
+        // a capture has a handful of finish blocks (1024 leaves each): one lane walks them
+        if (threadIdx.x == 0) {
+            const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
+            uint32_t a = nb0, o = 0, e = 0, epoch = 0;
+            for (uint32_t g = f0; g < f1; ++g) {
+                const uint4 s = sp.fsum[g];
+                sp.fbase[g] = make_uint4(a, o, e, epoch);
+                if (s.w) epoch = a + s.w - 1;
+                a += s.x;
+                o += s.y;
+                e += s.z;
+            }
+            uint64_t e0;
+            const uint64_t ne = cap_edges(sp.f, cap, e0);
+            if ((uint64_t)a > 2 * (ne + 1) + 512) atomicOr(sp.fallback, (uint32_t)kFbPool);
+            base_msg = atomicAdd((unsigned long long *)&sp.f.totals[0], (unsigned long long)o);
+            base_err = atomicAdd((unsigned long long *)&sp.f.totals[1], (unsigned long long)e);
+            sp.cap_base[2 * cap] = base_msg;
+            sp.cap_base[2 * cap + 1] = base_err;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ uint64_t pool_start(uint64_t e0, uint32_t cap) {
+    return 2 * (e0 + cap) + (uint64_t)cap * 512;    // 2 per leaf + 512 per capture
+}
+
+// append values by ordinal, error list, message descriptors (sample, epoch, count)
+__global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
+    __shared__ uint32_t sh[4][kFinBlock];
+    if (*sp.fallback) return;
+    const uint32_t total = sp.fin_off[sp.f.num_captures];
+    const uint32_t max_bits = sp.f.tables->max_bits;
+    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+        uint32_t cap, fb;
+        locate_fin(sp, g, cap, fb);
+        FinLeaf L;
+        fin_block_scan(sp, cap, fb, L, sh);
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t pool0 = pool_start(e0, cap);
+        if (pool0 + 2 * (ne + 1) + 512 > sp.app_capacity) {
+            if (threadIdx.x == 0) atomicOr(sp.fallback, (uint32_t)kFbPool);
+            continue;
+        }
+        uint8_t *vals = sp.app_vals + pool0;
+        const uint4 base = sp.fbase[g];
+        const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
+        if (fb == 0 && threadIdx.x < nb0) {
+            const uint32_t t = threadIdx.x;
+            vals[t] = (uint8_t)((sp.first.data[t >> 6] >> (t & 63)) & 1ull);
+        }
+        if (fb == 0 && threadIdx.x == 0 && nb0 > (uint32_t)kFinBlock) atomicOr(sp.fallback, (uint32_t)kFbPool);
+        if (!L.have) continue;
+        const uint32_t ai = base.x + L.a_in;
+        const uint32_t epoch = L.r_in ? base.x + L.r_in - 1 : base.w;
+        for (uint32_t j = 0; j < L.ev.napp && j < 32; ++j) vals[ai + j] = (uint8_t)((L.ev.appvals >> j) & 1u);
+        if (L.ev.nerr) {
+            const uint64_t slot = sp.cap_base[2 * cap + 1] + base.z + L.e_in;
+            if (slot < sp.err_capacity) sp.errs[slot] = L.ev.err_pos;
+        }
+        for (uint32_t j = 0; j < L.ev.nout && j < 2; ++j) {
+            const uint32_t ep = L.ev.out_rb[j] != 0xffu ? ai + L.ev.out_rb[j] : epoch;
+            const uint32_t have = ai + L.ev.out_ab[j] - ep;
+            const uint64_t slot = sp.cap_base[2 * cap] + base.y + L.o_in + j;
+            if (slot < sp.f.msg_capacity) {
+                MsgDev mm;
+                mm.capture = cap;
+                mm.reserved = 0;
+                mm.sample = L.ev.out_pos[j];
+                mm.payload[0] = (uint64_t)ep | ((uint64_t)have << 32);     // resolved by fin_msg_kernel
+                mm.payload[1] = mm.payload[2] = mm.payload[3] = 0;
+                sp.f.msgs[slot] = mm;
+            }
+        }
+        // outgoing state: the lane that owns the tail leaf
+        if ((uint64_t)fb * kFinBlock + threadIdx.x == ne) {
+            SegState so;
+            so.st.cur = L.ev.end_cur;
+            so.st.k = L.ev.end_k;
+            so.st.prev = L.ev.end_prev;
+            so.st.pad = 0;
+            const uint32_t ep_end = (L.ev.flags & 1u) ? ai + L.ev.apps_at_reset : epoch;
+            const uint32_t have = ai + L.ev.napp - ep_end;
+            so.st.nbits = have;
+            so.st.data[0] = ep_end;             // resolved by fin_msg_kernel
+            for (int q = 1; q < kPayloadWords; ++q) so.st.data[q] = 0;
+            if (L.ev.flags & 4u) {
+                // ended inside a skipped rest-of-buffer: reset, k = 0
+                so.st.cur = 0;
+                so.st.k = 0;
+            }
+            so.skip_to = 0;
+            so.pad = 0;
+            sp.final_state[cap] = so;
+        }
+    }
+}
+
+// gathers payload bits: one lane per message, then one per capture for the outgoing state
+__global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
+    if (*sp.fallback) return;
+    const uint32_t max_bits = sp.f.tables->max_bits;
+    const uint32_t nbytes = (max_bits + 7u) >> 3;
+    const uint64_t nmsg = min((uint64_t)sp.f.totals[0], sp.f.msg_capacity);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nmsg + sp.f.num_captures; m += stride) {
+        if (m < nmsg) {
+            MsgDev mm = sp.f.msgs[m];
+            uint64_t e0;
+            cap_edges(sp.f, mm.capture, e0);
+            const uint8_t *vals = sp.app_vals + pool_start(e0, mm.capture);
+            const uint32_t ep = (uint32_t)mm.payload[0], have = (uint32_t)(mm.payload[0] >> 32);
+            const uint32_t take = min(have, min(max_bits + 1, 256u));
+            uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            for (uint32_t t = 0; t < take; ++t) {
+                const uint64_t bit = vals[ep + t] ? (1ull << (t & 63)) : 0ull;
+                const uint32_t q = t >> 6;
+                w0 |= q == 0 ? bit : 0ull;
+                w1 |= q == 1 ? bit : 0ull;
+                w2 |= q == 2 ? bit : 0ull;
+                w3 |= q == 3 ? bit : 0ull;
+            }
+            const uint64_t wv[4] = {w0, w1, w2, w3};
+            for (uint32_t q = 0; q < 4; ++q) {
+                uint64_t v = wv[q];
+                if (8 * q >= nbytes) v = 0;
+                else if (8 * (q + 1) > nbytes) v &= (1ull << ((nbytes - 8 * q) * 8)) - 1ull;
+                mm.payload[q] = v;
+            }
+            sp.f.msgs[m] = mm;
+        } else {
+            const uint32_t cap = (uint32_t)(m - nmsg);
+            SegState so = sp.final_state[cap];
+            uint64_t e0;
+            cap_edges(sp.f, cap, e0);
+            const uint8_t *vals = sp.app_vals + pool_start(e0, cap);
+            const uint32_t ep = (uint32_t)so.st.data[0];
+            const uint32_t take = min(so.st.nbits, min(max_bits + 1, 320u));
+            for (int q = 0; q < kPayloadWords; ++q) so.st.data[q] = 0;
+            for (uint32_t t = 0; t < take; ++t) {
+                if (vals[ep + t]) so.st.data[t >> 6] |= 1ull << (t & 63);
+            }
+            sp.final_state[cap] = so;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------
+
+uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S) {
+    // 64 leaves per block: about one simulation task per lane, and the tables
+    // (~35 KiB for the shipped devices) let several workgroups share a CU
+    uint32_t lb = 64;
+    while (lb > 16 && block_lds_bytes(lb, D, S) > 140u * 1024u) lb >>= 1;
+    return lb;
+}
+
+uint32_t fsm_scan_fin_block() { return (uint32_t)kFinBlock; }
+
+hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
+    ScanParams sp{};
+    sp.f = a.f;
+    sp.block_tab = a.block_tab;
+    sp.block_in = a.block_in;
+    sp.cap_block_off = a.cap_block_off;
+    sp.events = a.events;
+    sp.app_vals = a.app_vals;
+    sp.app_capacity = a.app_capacity;
+    sp.errs = a.errs;
+    sp.err_capacity = a.err_capacity;
+    sp.have_first = a.first ? 1 : 0;
+    if (a.first) sp.first = *a.first;
+    sp.final_state = a.final_state;
+    sp.fallback = a.fallback;
+    sp.total_blocks_cap = a.total_blocks_cap;
+    sp.leaf_block = a.leaf_block;
+    sp.fin_off = a.fin_off;
+    sp.fsum = reinterpret_cast<uint4 *>(a.fsum);
+    sp.fbase = reinterpret_cast<uint4 *>(a.fbase);
+    sp.cap_base = a.cap_base;
+    sp.fin_blocks_cap = a.fin_blocks_cap;
+    sp.leaf_res = a.leaf_res;
+    sp.Dp = (a.D + 7u) & ~7u;
+    const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S);
+    const size_t lds_blocks = ((size_t)kStageBlocks * sp.Dp + (size_t)kSuperGroups * a.D) * 2 + 64;
+    if (lds_blocks > 150u * 1024u) return hipErrorInvalidValue;
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_leaf_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_emit_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_blocks_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blocks);
+    if (e != hipSuccess) return e;
+    const uint32_t caps = a.f.num_captures;
+    const uint32_t cap_grid = caps < 256 ? caps : 256;
+    hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
+    hipLaunchKernelGGL(scan_leaf_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(cap_grid), dim3(kScanThreads), lds_blocks, stream, sp);
+    hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
+    hipLaunchKernelGGL(fin_sum_kernel, dim3(a.grid_blocks), dim3(kFinBlock), 0, stream, sp);
+    hipLaunchKernelGGL(fin_scan_kernel, dim3(cap_grid), dim3(kScanThreads), 0, stream, sp);
+    hipLaunchKernelGGL(fin_write_kernel, dim3(a.grid_blocks), dim3(kFinBlock), 0, stream, sp);
+    hipLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, sp);
+    return hipGetLastError();
+}
+
+}  // namespace ookd

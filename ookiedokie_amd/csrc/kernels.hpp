@@ -62,6 +62,7 @@ constexpr int kScanGroup = 1024;        // blocks per first-level scan group
 struct EdgeParams {
     const uint64_t *bits;
     uint64_t words_per_cap;
+    uint64_t n_out;             // decimated samples per capture: no edge at or beyond it
     uint32_t num_captures;
     uint32_t blocks_per_cap;    // words_per_cap / kBlockWords
     uint32_t *blk_count;        // [captures * blocks_per_cap]
@@ -151,6 +152,50 @@ hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state
 hipError_t launch_fsm_round(const FsmParams &p, uint32_t parity, uint32_t mode, uint32_t slot,
                             hipStream_t stream);
 hipError_t launch_fsm_gather(const FsmParams &p, hipStream_t stream);
+
+// ---- state machine as a scan over edges (fsm_scan.hip) -----------------------------
+
+struct LeafEvDev {              // what happened in one edge-to-edge span
+    uint8_t napp, nout, nerr;
+    uint8_t flags;              // bit0: passed through reset; bit2: ends inside a skipped rest-of-buffer
+    uint8_t apps_at_reset;      // appends of this span before its last reset
+    uint8_t out_ab[2];          // appends of this span before output j
+    uint8_t out_rb[2];          // apps_at_reset as of output j (0xff: no reset before it in this span)
+    uint8_t end_cur, end_prev, pad;
+    uint32_t appvals;           // bit j = value of the j-th append
+    uint32_t end_k;
+    uint64_t out_pos[2];
+    uint64_t err_pos;
+};
+static_assert(sizeof(LeafEvDev) == 48, "LeafEvDev layout");
+
+struct FsmScanArgs {
+    FsmParams f;                // tables, edges, geometry, msgs / totals
+    uint32_t D, S;              // abstract states, machine states
+    uint32_t leaf_block;        // from fsm_scan_leaf_block()
+    uint32_t grid_blocks;       // persistent workgroups for the leaf / emit kernels
+    uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
+    uint32_t *leaf_res;         // [edges + captures][2S+2]
+    uint16_t *block_in;         // [total_blocks_cap]
+    uint32_t *cap_block_off;    // [captures + 1]
+    uint32_t total_blocks_cap;
+    LeafEvDev *events;          // [edges + captures]
+    uint8_t *app_vals;          // append pool
+    uint64_t app_capacity;
+    uint64_t *errs;             // flat error list
+    uint64_t err_capacity;
+    const FsmStateDev *first;   // incoming state (host pointer) or null = reset
+    SegState *final_state;      // [captures]
+    uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
+    uint32_t *fin_off;          // [captures + 1]
+    void *fsum, *fbase;         // [fin_blocks_cap] x 16 B each
+    unsigned long long *cap_base;   // [captures * 2]
+    uint32_t fin_blocks_cap;
+};
+
+uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);
+uint32_t fsm_scan_fin_block();
+hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 
 // ---- unpack (backend rx) ----------------------------------------------------
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream);

@@ -35,7 +35,7 @@ struct ResultHeader {
     uint64_t totals[2];
     unsigned long long recompute;
     uint32_t total_edges;
-    uint32_t pad;
+    uint32_t scan_fallback;
 };
 
 template <typename T>
@@ -248,6 +248,23 @@ struct ookd_rx {
     DevBuf<uint64_t> d_seg_errs;
     DevBuf<ResultHeader> d_hdr;
     DevBuf<uint64_t> d_debug;
+
+    // scan form of the state machine (fsm_scan.hip)
+    bool scan_ok = false;           // device fits the scan's tables and it was not disabled
+    bool scan_used = false;         // the results of the last run come from the scan
+    uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
+    uint32_t scan_max_bits = 0;
+    DevBuf<uint16_t> d_block_tab, d_block_in;
+    DevBuf<uint32_t> d_leaf_res;
+    DevBuf<uint32_t> d_cap_block_off;
+    DevBuf<LeafEvDev> d_events;
+    DevBuf<uint8_t> d_app_vals;
+    DevBuf<uint64_t> d_scan_errs;
+    DevBuf<SegState> d_final_state;
+    DevBuf<uint32_t> d_fin_off;
+    DevBuf<uint64_t> d_fsum, d_fbase;       // 16 B per finish block
+    DevBuf<unsigned long long> d_cap_base;
+    uint32_t scan_fin_cap = 0;
     DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
 
     ResultHeader *h_hdr = nullptr;  // pinned
@@ -283,6 +300,18 @@ struct ookd_rx {
         d_seg_errs.release();
         d_hdr.release();
         d_debug.release();
+        d_block_tab.release();
+        d_leaf_res.release();
+        d_block_in.release();
+        d_cap_block_off.release();
+        d_events.release();
+        d_app_vals.release();
+        d_scan_errs.release();
+        d_final_state.release();
+        d_fin_off.release();
+        d_fsum.release();
+        d_fbase.release();
+        d_cap_base.release();
         d_stage_in.release();
         if (h_hdr) (void)hipHostFree(h_hdr);
         if (h_msgs) (void)hipHostFree(h_msgs);
@@ -328,6 +357,7 @@ struct ookd_rx {
         EdgeParams e{};
         e.bits = d_bits.p;
         e.words_per_cap = run_words;
+        e.n_out = run_n_out;
         e.num_captures = run_caps;
         e.blocks_per_cap = run_blocks;
         e.blk_count = d_blk_count.p;
@@ -373,6 +403,8 @@ struct ookd_rx {
 
     int front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                         uint32_t halo_len);
+    int run_state_machine(const FsmStateDev *first, bool fresh);
+    int fsm_scan(const FsmStateDev *first);
     int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
     int fetch_results();
 };
@@ -465,6 +497,102 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
     return OOKD_OK;
 }
 
+// The state machine over the current edge list: scan form when possible,
+// segment/round form otherwise (or when the scan refuses the capture).
+int ookd_rx::run_state_machine(const FsmStateDev *first, bool fresh) {
+    scan_used = false;
+    stats.fsm_path = 0;
+    stats.fsm_fallback_reason = 0;
+    if (!have_fsm || run_n_out == 0) {
+        HIPCHK(hipEventRecord(ev[2], stream));
+        return OOKD_OK;
+    }
+    bool try_scan = scan_ok;
+    if (first && (first->cur >= scan_S || first->nbits > scan_max_bits + 1)) try_scan = false;
+    if (try_scan) {
+        int rc = fsm_scan(first);
+        if (rc != OOKD_OK) return rc;
+        if (h_hdr->scan_fallback == 0) {
+            scan_used = true;
+            stats.fsm_path = 1;
+            return OOKD_OK;
+        }
+        stats.fsm_fallback_reason = h_hdr->scan_fallback;
+        if (getenv("OOKD_DEBUG")) fprintf(stderr, "[ookd] fsm scan refused (reason %u), using rounds\n", h_hdr->scan_fallback);
+        // the refused scan may have touched the totals
+        HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
+        HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+    }
+    int rc = fsm_to_fixpoint(first, true, false);
+    if (rc != OOKD_OK) return rc;
+    stats.fsm_path = try_scan ? 3 : 2;
+    return OOKD_OK;
+}
+
+int ookd_rx::fsm_scan(const FsmStateDev *first) {
+    FsmScanArgs a{};
+    a.f = fsm_params();
+    a.D = scan_D;
+    a.S = scan_S;
+    a.leaf_block = scan_leaf_block;
+    a.grid_blocks = 1024;
+    a.block_tab = d_block_tab.p;
+    a.leaf_res = d_leaf_res.p;
+    a.block_in = d_block_in.p;
+    a.cap_block_off = d_cap_block_off.p;
+    a.total_blocks_cap = scan_blocks_cap;
+    a.events = d_events.p;
+    a.app_vals = d_app_vals.p;
+    a.app_capacity = d_app_vals.n;
+    a.errs = d_scan_errs.p;
+    a.err_capacity = d_scan_errs.n;
+    a.first = first;
+    a.final_state = d_final_state.p;
+    a.fallback = &d_hdr.p->scan_fallback;
+    a.fin_off = d_fin_off.p;
+    a.fsum = d_fsum.p;
+    a.fbase = d_fbase.p;
+    a.cap_base = d_cap_base.p;
+    a.fin_blocks_cap = scan_fin_cap;
+    HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
+    HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+    HIPCHK(launch_fsm_scan(a, stream));
+    HIPCHK(hipEventRecord(ev[2], stream));
+    HIPCHK(hipMemcpyAsync(&h_hdr->scan_fallback, &d_hdr.p->scan_fallback, sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (getenv("OOKD_DEBUG_SCAN") && d_debug.p) {
+        uint64_t dbg[32];
+        HIPCHK(hipMemcpy(dbg, d_debug.p, sizeof(dbg), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i)
+            fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans\n", i,
+                    (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
+                    (unsigned long long)dbg[4 * i + 2], (unsigned long long)dbg[4 * i + 3]);
+    }
+    if (getenv("OOKD_DEBUG_SCAN") && getenv("OOKD_DEBUG_SCAN")[0] == '2') {
+        uint32_t off[2];
+        HIPCHK(hipMemcpy(off, d_cap_block_off.p, 8, hipMemcpyDeviceToHost));
+        uint32_t ne32[2];
+        HIPCHK(hipMemcpy(&ne32[0], d_blk_offset.p, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&ne32[1], d_blk_offset.p + run_blocks, 4, hipMemcpyDeviceToHost));
+        const uint32_t ne = ne32[1] - ne32[0];
+        fprintf(stderr, "[scan] blocks %u..%u ne %u D %u LB %u\n", off[0], off[1], ne, scan_D, scan_leaf_block);
+        std::vector<uint16_t> bin(off[1] ? off[1] : 1), btab((size_t)(off[1] ? off[1] : 1) * scan_D);
+        if (off[1]) {
+            HIPCHK(hipMemcpy(bin.data(), d_block_in.p, off[1] * 2, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(btab.data(), d_block_tab.p, (size_t)off[1] * scan_D * 2, hipMemcpyDeviceToHost));
+            for (uint32_t b = 0; b < off[1] && b < 4; ++b)
+                fprintf(stderr, "[scan] block %u in %u -> out %u\n", b, bin[b], btab[(size_t)b * scan_D + bin[b]]);
+        }
+        std::vector<LeafEvDev> evs(ne + 1);
+        HIPCHK(hipMemcpy(evs.data(), d_events.p, (ne + 1) * sizeof(LeafEvDev), hipMemcpyDeviceToHost));
+        for (uint32_t i = ne > 6 ? ne - 6 : 0; i <= ne; ++i)
+            fprintf(stderr, "[scan] leaf %u napp %u nout %u nerr %u flags %u end cur %u k %u prev %u\n", i,
+                    evs[i].napp, evs[i].nout, evs[i].nerr, evs[i].flags, evs[i].end_cur, evs[i].end_k, evs[i].end_prev);
+    }
+    return OOKD_OK;
+}
+
 int ookd_rx::fetch_results() {
     HIPCHK(hipMemcpyAsync(h_hdr, d_hdr.p, sizeof(ResultHeader), hipMemcpyDeviceToHost, stream));
     const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
@@ -496,7 +624,7 @@ int ookd_rx::fetch_results() {
         return OOKD_ERR_CAPACITY;
     }
     if (have_fsm && run_n_out > 0) {
-        if (h_hdr->flags & 1u) {
+        if (!scan_used && (h_hdr->flags & 1u)) {
             set_error("a state machine segment produced more than %u messages "
                       "(raise ookd_rx_config.message_slots)", msg_slots);
             return OOKD_ERR_CAPACITY;
@@ -514,6 +642,12 @@ int ookd_rx::fetch_results() {
         num_msgs = total;
         stats.num_messages = total;
         stats.num_errors = h_hdr->totals[1];
+        if (scan_used && run_caps > 1) {
+            // the scan emits each capture's messages contiguously and in order, but
+            // captures land in the order their workgroups finish
+            std::stable_sort(h_msgs, h_msgs + total,
+                             [](const MsgDev &x, const MsgDev &y) { return x.capture < y.capture; });
+        }
     }
     return OOKD_OK;
 }
@@ -653,7 +787,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rx->max_blocks = blocks;
     rx->max_segs_per_cap = std::max<uint32_t>(segs, 1);
     const uint64_t total_out = rx->max_n_out * rx->max_captures;
-    rx->edge_capacity = cfg->edge_capacity ? cfg->edge_capacity : total_out / 16 + (1u << 20);
+    rx->edge_capacity = cfg->edge_capacity ? cfg->edge_capacity : total_out / 32 + (1u << 20);
     if (rx->edge_capacity > 0xfffffff0ull) rx->edge_capacity = 0xfffffff0ull;
     rx->msg_capacity = cfg->message_capacity
                            ? cfg->message_capacity
@@ -680,6 +814,28 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rc |= rx->d_seg_err_count.alloc(nseg);
         rc |= rx->d_seg_errs.alloc(nseg * rx->err_slots);
         if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4);
+        // scan form: abstract states = states x bit counts + skip x2 + poison
+        rx->scan_S = (uint32_t)device->state_duration_us.size();
+        rx->scan_max_bits = device->num_bits;
+        rx->scan_D = rx->scan_S * (device->num_bits + 2) + 3;
+        rx->scan_ok = !(cfg->flags & OOKD_RX_FSM_ROUNDS) && rx->scan_D <= 384 && device->num_bits <= 254;
+        if (rx->scan_ok) {
+            rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
+            rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
+            rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
+            rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
+            rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
+            rc |= rx->d_cap_block_off.alloc(caps + 1);
+            rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
+            rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
+            rc |= rx->d_scan_errs.alloc(1u << 16);
+            rc |= rx->d_final_state.alloc(caps);
+            rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
+            rc |= rx->d_fin_off.alloc(caps + 1);
+            rc |= rx->d_fsum.alloc(2 * (size_t)rx->scan_fin_cap);
+            rc |= rx->d_fbase.alloc(2 * (size_t)rx->scan_fin_cap);
+            rc |= rx->d_cap_base.alloc(2 * caps);
+        }
     }
     if (rc != OOKD_OK) return nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&rx->h_hdr), sizeof(ResultHeader)) != hipSuccess ||
@@ -718,7 +874,7 @@ int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
     rx->stats = ookd_rx_stats{};
     int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
     if (rc != OOKD_OK) return rc;
-    rc = rx->fsm_to_fixpoint(nullptr, true, false);
+    rc = rx->run_state_machine(nullptr, true);
     if (rc != OOKD_OK) return rc;
     return rx->fetch_results();
 }
@@ -784,14 +940,15 @@ int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, con
     int rc = rx->front_and_edges(d_iq, num_samples, hl ? rx->d_halo.p : nullptr, hl);
     if (rc != OOKD_OK) return rc;
     static_assert(sizeof(ookd_fsm_state) == sizeof(FsmStateDev), "fsm state layout");
-    rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), true, false);
+    rc = rx->run_state_machine(reinterpret_cast<const FsmStateDev *>(state_in), true);
     if (rc != OOKD_OK) return rc;
     rc = rx->fetch_results();
     if (rc != OOKD_OK) return rc;
     if (state_out && rx->have_fsm && rx->run_n_out > 0) {
         const size_t nseg = rx->run_segs_per_cap;
-        HIPCHK(hipMemcpy(state_out, &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)].st,
-                         sizeof(FsmStateDev), hipMemcpyDeviceToHost));
+        const SegState *src = rx->scan_used ? rx->d_final_state.p
+                                            : &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)];
+        HIPCHK(hipMemcpy(state_out, &src->st, sizeof(FsmStateDev), hipMemcpyDeviceToHost));
     } else if (state_out) {
         if (state_in) *state_out = *state_in;
         else memset(state_out, 0, sizeof(*state_out));
@@ -810,14 +967,21 @@ int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in, ookd_fsm_s
         if (state_out) *state_out = *state_in;
         return OOKD_OK;
     }
-    int rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), false, true);
+    int rc;
+    if (rx->scan_used) {
+        // the scan is cheap enough to simply run again from the new incoming state
+        rc = rx->run_state_machine(reinterpret_cast<const FsmStateDev *>(state_in), true);
+    } else {
+        rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), false, true);
+    }
     if (rc != OOKD_OK) return rc;
     rc = rx->fetch_results();
     if (rc != OOKD_OK) return rc;
     if (state_out) {
         const size_t nseg = rx->run_segs_per_cap;
-        HIPCHK(hipMemcpy(state_out, &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)].st,
-                         sizeof(FsmStateDev), hipMemcpyDeviceToHost));
+        const SegState *src = rx->scan_used ? rx->d_final_state.p
+                                            : &rx->d_state_out.p[(size_t)rx->final_parity * nseg + (nseg - 1)];
+        HIPCHK(hipMemcpy(state_out, &src->st, sizeof(FsmStateDev), hipMemcpyDeviceToHost));
     }
     return OOKD_OK;
 }
@@ -887,6 +1051,11 @@ int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity, 
     if (num) *num = rx->stats.num_errors;
     if (!rx->have_fsm || rx->run_n_out == 0 || !samples || capacity == 0) return OOKD_OK;
     HIPCHK(hipSetDevice(rx->dev));
+    if (rx->scan_used) {
+        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(rx->stats.num_errors, capacity), rx->d_scan_errs.n);
+        if (n) HIPCHK(hipMemcpy(samples, rx->d_scan_errs.p, n * 8, hipMemcpyDeviceToHost));
+        return OOKD_OK;
+    }
     const size_t nseg = (size_t)rx->run_caps * rx->run_segs_per_cap;
     std::vector<uint32_t> counts(nseg);
     std::vector<uint64_t> errs(nseg * rx->err_slots);

@@ -50,38 +50,46 @@ def _odev(oracle, name, rate=RATE):
 
 
 def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, check_fir=False,
-             segment_buffers=0, rate=RATE):
+             segment_buffers=0, rate=RATE, expect_scan=True):
+    """Runs the capture through BOTH forms of the state machine (scan of
+    per-edge transition functions; segment rounds) and checks each against
+    the oracle."""
     f = _flt(ok, filt)
     of = _ofir(oracle, filt)
     dec = of.total_decimation if of else 1
     d = _dev(ok, devname, rate // dec)
     od = _odev(oracle, devname, rate // dec)
     n = iq.size // 2
-    rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
-                     exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers)
-    got = rx.rx(iq)
     want = oracle.rx(iq, of, thr, od, spb, want_bits=True, want_fir=check_fir)
-    assert got.stats["decimated_samples"] == want.decimated
-    bits = rx.bits()
-    assert bits.size == want.bits.size
-    diff = np.nonzero(bits != want.bits)[0]
-    assert diff.size == 0, "first differing bit at %s" % diff[:5]
-    assert list(rx.edges()) == list(edges_of(want.bits))
-    assert list(got.msg_samples) == list(want.msg_samples)
-    assert (got.payloads == want.payloads).all()
-    errs, nerr = rx.errors()
-    assert nerr == len(want.err_samples)
-    if nerr <= 32:
-        assert list(errs) == list(want.err_samples)
-    if check_fir:
-        y = rx.fir_output()
-        if exact or of is None or of.num_stages != 1 or int(of.decimation[0]) != 1:
-            assert (y.view(np.uint32) == want.fir.view(np.uint32)).all(), "FIR floats not bit-identical"
-        else:
-            scale = float(np.abs(of.taps).sum()) * float(np.abs(iq).max()) / 2048.0
-            tol = FIR_RTOL * np.maximum(np.abs(want.fir), scale)
-            assert (np.abs(y - want.fir) <= tol).all()
-    rx.close()
+    got = None
+    for fsm_rounds in (False, True):
+        rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
+                         exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
+                         fsm_rounds=fsm_rounds)
+        got = rx.rx(iq)
+        assert got.stats["decimated_samples"] == want.decimated
+        if want.decimated:
+            assert got.stats["fsm_path"] == (2 if fsm_rounds else (1 if expect_scan else got.stats["fsm_path"]))
+        bits = rx.bits()
+        assert bits.size == want.bits.size
+        diff = np.nonzero(bits != want.bits)[0]
+        assert diff.size == 0, "first differing bit at %s" % diff[:5]
+        assert list(rx.edges()) == list(edges_of(want.bits))
+        assert list(got.msg_samples) == list(want.msg_samples), "fsm_rounds=%s" % fsm_rounds
+        assert (got.payloads == want.payloads).all(), "fsm_rounds=%s" % fsm_rounds
+        errs, nerr = rx.errors()
+        assert nerr == len(want.err_samples), "fsm_rounds=%s" % fsm_rounds
+        if nerr <= 32:
+            assert list(errs) == list(want.err_samples), "fsm_rounds=%s" % fsm_rounds
+        if check_fir and not fsm_rounds:
+            y = rx.fir_output()
+            if exact or of is None or of.num_stages != 1 or int(of.decimation[0]) != 1:
+                assert (y.view(np.uint32) == want.fir.view(np.uint32)).all(), "FIR floats not bit-identical"
+            else:
+                scale = float(np.abs(of.taps).sum()) * float(np.abs(iq).max()) / 2048.0
+                tol = FIR_RTOL * np.maximum(np.abs(want.fir), scale)
+                assert (np.abs(y - want.fir) <= tol).all()
+        rx.close()
     return got, want
 
 
@@ -238,20 +246,25 @@ def test_g7_tolerance_boundaries(ok, oracle, vectors):
     for c in g["cases"]:
         runs = mg.p3l_runs(g["payload_bits"], **{c["param"]: c["value"]})
         iq = _iq_from_stream(stream_from_runs(runs))
-        rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=g["spb"])
-        got = rx.rx(iq)
-        assert list(got.msg_samples) == c["msg_samples"], c
-        rx.close()
+        for fsm_rounds in (False, True):
+            rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=g["spb"],
+                             fsm_rounds=fsm_rounds)
+            got = rx.rx(iq)
+            assert list(got.msg_samples) == c["msg_samples"], (c, fsm_rounds)
+            rx.close()
 
 
-@pytest.mark.parametrize("segment_buffers", [1, 3, 0])
+@pytest.mark.parametrize("segment_buffers", [1, 3, 0, -1])
 def test_reference_fsm_fixtures_random_streams(ok, oracle, vectors, segment_buffers):
+    # segment_buffers >= 0: the round path with that segment size; -1: the scan path
+    fsm_rounds = segment_buffers >= 0
+    segment_buffers = max(segment_buffers, 0)
     for case in vectors["random_streams"]:
         d = _dev(ok, case["device"], case["rate"])
         iq = _iq_from_stream(stream_from_runs(case["runs"]))
         for buf, want in case["ref_fsm"].items():
             rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=int(buf),
-                             segment_buffers=segment_buffers)
+                             segment_buffers=segment_buffers, fsm_rounds=fsm_rounds)
             got = rx.rx(iq)
             # the file backend pads the capture to whole buffers; the fixtures
             # were cut at the end of the stream: ignore anything in the padding
@@ -276,11 +289,13 @@ def test_random_devices_match_oracle(ok, oracle):
                        * rng.uniform(0.8, 1.2))) for _ in range(int(rng.integers(20, 300)))]
         stream = stream_from_runs(runs)
         iq = _iq_from_stream(stream)
-        for spb, segb in ((97, 1), (512, 2), (4096, 3)):
-            # a random device may emit a message on every sample: one slot per sample
+        for spb, segb, fsm_rounds in ((97, 1, True), (512, 2, False), (4096, 3, True), (4096, 3, False)):
+            # a random device may emit a message on every sample: one slot per sample.
+            # fsm_rounds False: the scan runs where it can and hands over to the
+            # rounds where the device leaves its model -- either way the oracle's result.
             rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=spb,
                              segment_buffers=segb, message_slots=2 * spb * segb + 2,
-                             message_capacity=1 << 20, edge_capacity=iq.size)
+                             message_capacity=1 << 20, edge_capacity=iq.size, fsm_rounds=fsm_rounds)
             got = rx.rx(iq)
             want = oracle.rx(iq, None, 0.1, od, spb, msg_cap=1 << 20)
             assert list(got.msg_samples) == list(want.msg_samples), (it, spb)
