@@ -370,6 +370,10 @@ struct ScanParams {
     uint32_t fin_blocks_cap;
     uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
+    uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
+    uint16_t *group_tab;        // [groups][Dp]
+    uint16_t *group_in;         // [groups]
+    uint16_t *cap_end;          // [captures] state after the last regular leaf
 };
 
 namespace {
@@ -639,43 +643,52 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t count) {
 // prefix of per-capture block counts: scan blocks (regular leaves) and finish
 // blocks (all leaves); one workgroup
 __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp) {
-    __shared__ uint32_t part[kScanThreads], part2[kScanThreads];
+    __shared__ uint32_t part[kScanThreads], part2[kScanThreads], part3[kScanThreads];
     const uint32_t tid = threadIdx.x;
     const uint32_t nc = sp.f.num_captures;
     const uint32_t chunk = (nc + kScanThreads - 1) / kScanThreads;
     const uint32_t lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
-    uint32_t sum = 0, sum2 = 0;
+    uint32_t sum = 0, sum2 = 0, sum3 = 0;
     for (uint32_t c = lo; c < hi; ++c) {
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, c, e0);
         const uint64_t regular = ne > 1 ? ne - 1 : 0;
-        sum += (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        const uint32_t nblk = (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        sum += nblk;
         sum2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
+        sum3 += (nblk + 15u) / 16u;
     }
     part[tid] = sum;
     part2[tid] = sum2;
+    part3[tid] = sum3;
     __syncthreads();
     for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
         const uint32_t v = tid >= d ? part[tid - d] : 0u;
         const uint32_t v2 = tid >= d ? part2[tid - d] : 0u;
+        const uint32_t v3 = tid >= d ? part3[tid - d] : 0u;
         __syncthreads();
         part[tid] += v;
         part2[tid] += v2;
+        part3[tid] += v3;
         __syncthreads();
     }
-    uint32_t run = part[tid] - sum, run2 = part2[tid] - sum2;
+    uint32_t run = part[tid] - sum, run2 = part2[tid] - sum2, run3 = part3[tid] - sum3;
     for (uint32_t c = lo; c < hi; ++c) {
         sp.cap_block_off[c] = run;
         sp.fin_off[c] = run2;
+        sp.cap_group_off[c] = run3;
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, c, e0);
         const uint64_t regular = ne > 1 ? ne - 1 : 0;
-        run += (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        const uint32_t nblk = (uint32_t)((regular + sp.leaf_block - 1) / sp.leaf_block);
+        run += nblk;
         run2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
+        run3 += (nblk + 15u) / 16u;
     }
     if (tid == kScanThreads - 1) {
         sp.cap_block_off[nc] = part[tid];
         sp.fin_off[nc] = part2[tid];
+        sp.cap_group_off[nc] = part3[tid];
         if (part[tid] > sp.total_blocks_cap || part2[tid] > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
     }
 }
@@ -729,30 +742,64 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     }
 }
 
-// One workgroup per capture walks its block tables from the true start state.
-// Two levels so the walk is short: groups of 16 block tables are composed in
-// parallel, one lane walks the group tables, then one lane per group walks
+// Walk of the block tables from the true start state, three small kernels:
+// groups of 16 block tables are composed in parallel (one workgroup each),
+// one lane per capture walks the group tables, then one lane per group walks
 // its 16 blocks.
 constexpr int kGroup = 16;              // block tables per group
-constexpr int kStageBlocks = 128;       // block tables staged in LDS at a time
-constexpr int kSuperGroups = 64;        // groups per sequential super-chunk
 
-__global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(ScanParams sp) {
+__device__ __forceinline__ void locate_group(const ScanParams &sp, uint32_t gg, uint32_t &cap, uint32_t &lg) {
+    uint32_t lo = 0, hi = sp.f.num_captures;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sp.cap_group_off[mid] <= gg) lo = mid;
+        else hi = mid;
+    }
+    cap = lo;
+    lg = gg - sp.cap_group_off[lo];
+}
+
+// stage the block tables [b0, b0+nb) of one group into LDS
+__device__ __forceinline__ void stage_group(const ScanParams &sp, uint32_t b0, uint32_t nb, uint16_t *stage) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)b0 * sp.Dp);
+    uint4 *dst = reinterpret_cast<uint4 *>(stage);
+    for (uint32_t i = threadIdx.x; i < nb * (sp.Dp / 8); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
+    if (*sp.fallback) return;
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kGroup][Dp]
+    const uint32_t D = sp.f.tables->num_states * (sp.f.tables->max_bits + 2) + 3;
+    const uint32_t total = sp.cap_group_off[sp.f.num_captures];
+    for (uint32_t gg = blockIdx.x; gg < total; gg += gridDim.x) {
+        uint32_t cap, lg;
+        locate_group(sp, gg, cap, lg);
+        const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
+        const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
+        stage_group(sp, b0, nb, stage);
+        for (uint32_t d = threadIdx.x; d < D; d += blockDim.x) {
+            uint32_t s = d;
+            for (uint32_t j = 0; j < nb; ++j) s = stage[j * sp.Dp + s];
+            sp.group_tab[(size_t)gg * sp.Dp + d] = (uint16_t)s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) {
     __shared__ LTab T;
     __shared__ uint32_t x;
-    __shared__ uint16_t gin[kSuperGroups];
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
-    const uint32_t D = T.D;
-    const uint32_t Dp = sp.Dp;                                              // row pitch, multiple of 8 entries
-    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);              // [kStageBlocks][Dp]
-    uint16_t *gtab = stage + (size_t)kStageBlocks * Dp;                     // [kSuperGroups][D]
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 group tables at a time
+    const uint32_t max_stage = 128;
     for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, cap, e0);
         const uint64_t *edges = sp.f.edges + e0;
-        const uint32_t b0 = sp.cap_block_off[cap], b1 = sp.cap_block_off[cap + 1];
+        const uint32_t g0 = sp.cap_group_off[cap], g1 = sp.cap_group_off[cap + 1];
         if (threadIdx.x == 0) {
             PSim f;
             Acc a;
@@ -760,58 +807,44 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocks_kernel(ScanParams sp
             x = encode_post(T, f, a, alive);
         }
         __syncthreads();
-        for (uint32_t sc = b0; sc < b1; sc += kSuperGroups * kGroup) {
-            const uint32_t sc_end = min(sc + (uint32_t)(kSuperGroups * kGroup), b1);
-            const uint32_t ng = (sc_end - sc + kGroup - 1) / kGroup;
-            // pass 1: group tables
-            for (uint32_t cb = sc; cb < sc_end; cb += kStageBlocks) {
-                const uint32_t nb = min((uint32_t)kStageBlocks, sc_end - cb);
-                {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)cb * Dp);
-                    uint4 *dst = reinterpret_cast<uint4 *>(stage);
-                    for (uint32_t i = threadIdx.x; i < nb * (Dp / 8); i += blockDim.x) dst[i] = src[i];
-                }
-                __syncthreads();
-                const uint32_t ngl = (nb + kGroup - 1) / kGroup;
-                for (uint32_t item = threadIdx.x; item < ngl * D; item += blockDim.x) {
-                    const uint32_t g = item / D, d = item - g * D;
-                    const uint32_t j1 = min((g + 1) * kGroup, nb);
-                    uint32_t s = d;
-                    for (uint32_t j = g * kGroup; j < j1; ++j) s = stage[j * Dp + s];
-                    gtab[((cb - sc) / kGroup + g) * D + d] = (uint16_t)s;
-                }
-                __syncthreads();
+        for (uint32_t gs = g0; gs < g1; gs += max_stage) {
+            const uint32_t ng = min(max_stage, g1 - gs);
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(sp.group_tab + (size_t)gs * sp.Dp);
+                uint4 *dst = reinterpret_cast<uint4 *>(stage);
+                for (uint32_t i = threadIdx.x; i < ng * (sp.Dp / 8); i += blockDim.x) dst[i] = src[i];
             }
-            // walk the groups
+            __syncthreads();
             if (threadIdx.x == 0) {
                 uint32_t s = x;
                 for (uint32_t g = 0; g < ng; ++g) {
-                    gin[g] = (uint16_t)s;
-                    s = gtab[g * D + s];
+                    sp.group_in[gs + g] = (uint16_t)s;
+                    s = stage[g * sp.Dp + s];
                 }
                 x = s;
             }
             __syncthreads();
-            // pass 2: state entering every block
-            for (uint32_t cb = sc; cb < sc_end; cb += kStageBlocks) {
-                const uint32_t nb = min((uint32_t)kStageBlocks, sc_end - cb);
-                {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)cb * Dp);
-                    uint4 *dst = reinterpret_cast<uint4 *>(stage);
-                    for (uint32_t i = threadIdx.x; i < nb * (Dp / 8); i += blockDim.x) dst[i] = src[i];
-                }
-                __syncthreads();
-                const uint32_t ngl = (nb + kGroup - 1) / kGroup;
-                if (threadIdx.x < ngl) {
-                    const uint32_t g = threadIdx.x;
-                    const uint32_t j1 = min((g + 1) * kGroup, nb);
-                    uint32_t s = gin[(cb - sc) / kGroup + g];
-                    for (uint32_t j = g * kGroup; j < j1; ++j) {
-                        sp.block_in[cb + j] = (uint16_t)s;
-                        s = stage[j * Dp + s];
-                    }
-                }
-                __syncthreads();
+        }
+        if (threadIdx.x == 0) sp.cap_end[cap] = (uint16_t)x;     // state after the last regular leaf
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_blockin_kernel(ScanParams sp) {
+    if (*sp.fallback) return;
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);
+    const uint32_t total = sp.cap_group_off[sp.f.num_captures];
+    for (uint32_t gg = blockIdx.x; gg < total; gg += gridDim.x) {
+        uint32_t cap, lg;
+        locate_group(sp, gg, cap, lg);
+        const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
+        const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
+        stage_group(sp, b0, nb, stage);
+        if (threadIdx.x == 0) {
+            uint32_t s = sp.group_in[gg];
+            for (uint32_t j = 0; j < nb; ++j) {
+                sp.block_in[b0 + j] = (uint16_t)s;
+                s = stage[j * sp.Dp + s];
             }
         }
         __syncthreads();
@@ -912,8 +945,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     const bool al0 = first_leaf(T, sp, edges, ne, f0, a0);
                     in = encode_post(T, f0, a0, al0);
                 } else {
-                    const uint32_t lastb = sp.cap_block_off[cap + 1] - 1;
-                    in = sp.block_tab[(size_t)lastb * sp.Dp + sp.block_in[lastb]];
+                    in = sp.cap_end[cap];
                 }
                 const uint64_t pos0 = edges[ne - 1] + 1;
                 Span tail;
@@ -1234,9 +1266,14 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.fin_blocks_cap = a.fin_blocks_cap;
     sp.leaf_res = a.leaf_res;
     sp.Dp = (a.D + 7u) & ~7u;
+    sp.cap_group_off = a.cap_group_off;
+    sp.group_tab = a.group_tab;
+    sp.group_in = a.group_in;
+    sp.cap_end = a.cap_end;
     const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S);
-    const size_t lds_blocks = ((size_t)kStageBlocks * sp.Dp + (size_t)kSuperGroups * a.D) * 2 + 64;
-    if (lds_blocks > 150u * 1024u) return hipErrorInvalidValue;
+    const size_t lds_group = (size_t)kGroup * sp.Dp * 2;
+    const size_t lds_walk = (size_t)128 * sp.Dp * 2;
+    if (lds_walk > 150u * 1024u) return hipErrorInvalidValue;
     hipError_t e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_leaf_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1244,14 +1281,16 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_emit_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_blocks_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blocks);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_walk_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk);
     if (e != hipSuccess) return e;
     const uint32_t caps = a.f.num_captures;
     const uint32_t cap_grid = caps < 256 ? caps : 256;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
     hipLaunchKernelGGL(scan_leaf_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(cap_grid), dim3(kScanThreads), lds_blocks, stream, sp);
+    hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
+    hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
+    hipLaunchKernelGGL(scan_blockin_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
     hipLaunchKernelGGL(fin_sum_kernel, dim3(a.grid_blocks), dim3(kFinBlock), 0, stream, sp);
     hipLaunchKernelGGL(fin_scan_kernel, dim3(cap_grid), dim3(kScanThreads), 0, stream, sp);

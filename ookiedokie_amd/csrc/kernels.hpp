@@ -191,6 +191,10 @@ struct FsmScanArgs {
     void *fsum, *fbase;         // [fin_blocks_cap] x 16 B each
     unsigned long long *cap_base;   // [captures * 2]
     uint32_t fin_blocks_cap;
+    uint32_t *cap_group_off;    // [captures + 1]
+    uint16_t *group_tab;        // [total_blocks_cap / 16 + captures + 1][D rounded up to 8]
+    uint16_t *group_in;         // same count
+    uint16_t *cap_end;          // [captures]
 };
 
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);

@@ -252,10 +252,14 @@ struct ookd_rx {
     // scan form of the state machine (fsm_scan.hip)
     bool scan_ok = false;           // device fits the scan's tables and it was not disabled
     bool scan_used = false;         // the results of the last run come from the scan
+    bool scan_pending = false;      // a scan is queued; its verdict is read with the results
+    bool pending_first_valid = false;
+    FsmStateDev pending_first{};
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab, d_block_in;
-    DevBuf<uint32_t> d_leaf_res;
+    DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
+    DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
     DevBuf<uint8_t> d_app_vals;
@@ -302,6 +306,10 @@ struct ookd_rx {
         d_debug.release();
         d_block_tab.release();
         d_leaf_res.release();
+        d_cap_group_off.release();
+        d_group_tab.release();
+        d_group_in.release();
+        d_cap_end.release();
         d_block_in.release();
         d_cap_block_off.release();
         d_events.release();
@@ -500,7 +508,9 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
 // The state machine over the current edge list: scan form when possible,
 // segment/round form otherwise (or when the scan refuses the capture).
 int ookd_rx::run_state_machine(const FsmStateDev *first, bool fresh) {
+    (void)fresh;
     scan_used = false;
+    scan_pending = false;
     stats.fsm_path = 0;
     stats.fsm_fallback_reason = 0;
     if (!have_fsm || run_n_out == 0) {
@@ -510,22 +520,18 @@ int ookd_rx::run_state_machine(const FsmStateDev *first, bool fresh) {
     bool try_scan = scan_ok;
     if (first && (first->cur >= scan_S || first->nbits > scan_max_bits + 1)) try_scan = false;
     if (try_scan) {
+        // queued without a host sync; fetch_results() looks at the scan's verdict
+        // and, if it refused the capture, runs the round path instead
+        pending_first_valid = first != nullptr;
+        if (first) pending_first = *first;
         int rc = fsm_scan(first);
         if (rc != OOKD_OK) return rc;
-        if (h_hdr->scan_fallback == 0) {
-            scan_used = true;
-            stats.fsm_path = 1;
-            return OOKD_OK;
-        }
-        stats.fsm_fallback_reason = h_hdr->scan_fallback;
-        if (getenv("OOKD_DEBUG")) fprintf(stderr, "[ookd] fsm scan refused (reason %u), using rounds\n", h_hdr->scan_fallback);
-        // the refused scan may have touched the totals
-        HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
-        HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+        scan_pending = true;
+        return OOKD_OK;
     }
     int rc = fsm_to_fixpoint(first, true, false);
     if (rc != OOKD_OK) return rc;
-    stats.fsm_path = try_scan ? 3 : 2;
+    stats.fsm_path = 2;
     return OOKD_OK;
 }
 
@@ -538,6 +544,10 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
     a.leaf_res = d_leaf_res.p;
+    a.cap_group_off = d_cap_group_off.p;
+    a.group_tab = d_group_tab.p;
+    a.group_in = d_group_in.p;
+    a.cap_end = d_cap_end.p;
     a.block_in = d_block_in.p;
     a.cap_block_off = d_cap_block_off.p;
     a.total_blocks_cap = scan_blocks_cap;
@@ -558,9 +568,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
     HIPCHK(launch_fsm_scan(a, stream));
     HIPCHK(hipEventRecord(ev[2], stream));
-    HIPCHK(hipMemcpyAsync(&h_hdr->scan_fallback, &d_hdr.p->scan_fallback, sizeof(uint32_t),
-                          hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    if (getenv("OOKD_DEBUG_SCAN")) HIPCHK(hipStreamSynchronize(stream));
     if (getenv("OOKD_DEBUG_SCAN") && d_debug.p) {
         uint64_t dbg[32];
         HIPCHK(hipMemcpy(dbg, d_debug.p, sizeof(dbg), hipMemcpyDeviceToHost));
@@ -605,6 +613,25 @@ int ookd_rx::fetch_results() {
                               sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     }
     HIPCHK(hipStreamSynchronize(stream));
+    if (scan_pending) {
+        scan_pending = false;
+        if (h_hdr->scan_fallback == 0) {
+            scan_used = true;
+            stats.fsm_path = 1;
+        } else {
+            // the scan refused this capture: run the round path and fetch again
+            stats.fsm_fallback_reason = h_hdr->scan_fallback;
+            if (getenv("OOKD_DEBUG")) {
+                fprintf(stderr, "[ookd] fsm scan refused (reason %u), using rounds\n", h_hdr->scan_fallback);
+            }
+            HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
+            HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+            int rc = fsm_to_fixpoint(pending_first_valid ? &pending_first : nullptr, true, false);
+            if (rc != OOKD_OK) return rc;
+            stats.fsm_path = 3;
+            return fetch_results();
+        }
+    }
     total_edges = run_n_out > 0 ? h_hdr->total_edges : 0;
     num_msgs = 0;
     stats.num_edges = total_edges;
@@ -823,6 +850,13 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
             rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
+            {
+                const size_t ngroups = rx->scan_blocks_cap / 16 + caps + 8;
+                rc |= rx->d_cap_group_off.alloc(caps + 1);
+                rc |= rx->d_group_tab.alloc(ngroups * ((rx->scan_D + 7u) & ~7u) + 64);
+                rc |= rx->d_group_in.alloc(ngroups);
+                rc |= rx->d_cap_end.alloc(caps + 8);
+            }
             rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
             rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
             rc |= rx->d_cap_block_off.alloc(caps + 1);
