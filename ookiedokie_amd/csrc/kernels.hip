@@ -218,37 +218,44 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
     }
 
     // ---- threshold, guard band, pack -----------------------------------------
+    // Per output: power (packed square + add), one compare per bound whose
+    // wave-wide result lands in an SGPR pair, and the lane's own bit shifted
+    // into `mask` through the carry (r runs downwards so bit r ends at position
+    // r).  The "inside the guard band" masks are OR-ed on the scalar unit.
     const uint64_t o0 = t0 + (uint64_t)tid * R;
     uint32_t mask = 0;
-    if (EXACT) {
+    uint64_t any_unsure = 0;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        float pw;
+        if (EXACT) {
+            pw = power_ref(acc[r].x, acc[r].y);
+        } else {
+            v2f sq;
+            asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(acc[r]));
+            pw = sq.x + sq.y;
+        }
+        const uint64_t ge_hi = __ballot(pw >= (EXACT ? p.p_star : p.p_hi));
+        asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mask) : "s"(ge_hi) : "vcc");
+        if (!EXACT) any_unsure |= __ballot(pw >= p.p_lo) & ~ge_hi;
+    }
+    if (!EXACT && any_unsure != 0) {
+        // some lane of this wave has a sample inside the band: those lanes redo
+        // their borderline samples in the reference's exact order
+        uint32_t redo = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float pw = power_ref(acc[r].x, acc[r].y);
-            mask |= (pw >= p.p_star ? 1u : 0u) << r;
-        }
-    } else {
-        uint32_t unsure = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float pw = power_ref(acc[r].x, acc[r].y);
-            mask |= (pw >= p.p_hi ? 1u : 0u) << r;
-            unsure |= ((pw >= p.p_lo && !(pw >= p.p_hi)) ? 1u : 0u) << r;
-        }
-        if (unsure) {
-            uint32_t redo = 0;
-            for (int r = 0; r < R; ++r) {
-                if ((unsure >> r) & 1u) {
-                    if (o0 + r < p.n_out) {
-                        const float2 y = fir1_exact_output(lds, Tp + R * tid + r, p.taps,
-                                                           p.stage[0].ntaps);
-                        const float pw = power_ref(y.x, y.y);
-                        mask |= (pw >= p.p_star ? 1u : 0u) << r;
-                        redo++;
-                    }
-                }
+            v2f sq;
+            asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(acc[r]));
+            const float pf = sq.x + sq.y;
+            if (pf >= p.p_lo && !(pf >= p.p_hi) && o0 + r < p.n_out) {
+                const float2 y = fir1_exact_output(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps);
+                const float pe = power_ref(y.x, y.y);
+                mask = (mask & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
+                redo++;
             }
-            if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
         }
+        if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
     }
     // outputs past the end of the (padded) capture do not exist
     if (o0 + R > p.n_out) {
