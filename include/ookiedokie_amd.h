@@ -155,7 +155,13 @@ enum {
      * state machine runs as a scan of per-edge transition functions and
      * falls back to this path only when a capture leaves the scan's model
      * (results are identical either way). */
-    OOKD_RX_FSM_ROUNDS = 1u << 2
+    OOKD_RX_FSM_ROUNDS = 1u << 2,
+    /* Front end: never take the "quiet" shortcut.  By default a wavefront whose
+     * whole input window is provably too small to reach the threshold
+     * (sqrt(2) * sum|taps| * max|sample| < threshold) emits its 1024 zero bits
+     * without running the filter -- the bits are identical, captures that are
+     * mostly silence run at memory speed.  Set this to time the worst case. */
+    OOKD_RX_NO_QUIET_SKIP = 1u << 3
 };
 
 typedef struct ookd_rx_config {

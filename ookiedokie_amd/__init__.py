@@ -38,6 +38,7 @@ FILE_EOF = -(2 ** 31)                   # SDR_FILE_EOF, sdr.h:36
 RX_EXACT_FIR = 1
 RX_KEEP_FIR = 2
 RX_FSM_ROUNDS = 4
+RX_NO_QUIET_SKIP = 8
 DEFAULT_THRESHOLD = 0.1                 # ookiedokie_cfg.c:27
 DEFAULT_RATE = 3000000                  # ookiedokie_cfg.c:32
 DEFAULT_SAMPLES_PER_BUF = 8192          # ookiedokie_cfg.c:34
@@ -380,11 +381,12 @@ class Receiver:
                  samples_per_buffer: int = DEFAULT_SAMPLES_PER_BUF, hip_device: int = 0,
                  max_captures: int = 1, exact_fir: bool = False, keep_fir: bool = False,
                  edge_capacity: int = 0, segment_buffers: int = 0, message_slots: int = 0,
-                 message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False):
+                 message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
+                 quiet_skip: bool = True):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
-                     | (RX_FSM_ROUNDS if fsm_rounds else 0))
+                     | (RX_FSM_ROUNDS if fsm_rounds else 0) | (0 if quiet_skip else RX_NO_QUIET_SKIP))
         cfg.threshold = threshold
         cfg.samples_per_buffer = samples_per_buffer
         cfg.max_samples = max_samples

@@ -66,9 +66,12 @@ __device__ __forceinline__ float power_ref(float re, float im) {
 // front end, 1 stage / decimation 1 (fs32_fs4, the 255-tap config)
 // ---------------------------------------------------------------------------
 //
-// One workgroup = 256 lanes = 4096 consecutive outputs; lane t owns outputs
-// 16t..16t+15 and keeps their 32 partial sums in registers.  The tile's
-// inputs plus the (padded) tap history are unpacked ONCE into LDS as float2.
+// One wavefront = 64 lanes = 1024 consecutive outputs, working alone (a
+// workgroup is just kFirWaves of them sharing an LDS allocation, no barrier);
+// lane t owns outputs 16t..16t+15 and keeps their 32 partial sums in
+// registers.  The wave loads its inputs plus the (padded) tap history raw,
+// decides from them whether the filter can be skipped (quiet test), and
+// otherwise unpacks them ONCE into its LDS window as float2.
 // Taps are consumed in chunks of 32 held in SGPRs; within a chunk the lane
 // streams 47 consecutive LDS samples, newest first, each feeding up to 16
 // accumulators -- so every output sees its taps in the reference order
@@ -79,7 +82,12 @@ __device__ __forceinline__ float power_ref(float re, float im) {
 // free for ds_read_b64 (32-lane halves, 64 banks), and keeps every read of
 // the unrolled body at  lane_base + compile-time immediate.
 
-__device__ __forceinline__ uint32_t slot(uint32_t j) { return j + (j >> 4); }
+__host__ __device__ __forceinline__ uint32_t slot(uint32_t j) { return j + (j >> 4); }
+
+// float2 slots of one wavefront's private window (kept a multiple of 2 = 16 B)
+__host__ __device__ __forceinline__ uint32_t fir1_wave_slots(uint32_t Tp) {
+    return (slot(kWaveTile + Tp) + 2u) & ~1u;
+}
 
 // Sequential, unfused recomputation of one output (guard-band path).
 __device__ __noinline__ float2 fir1_exact_output(const float2 *lds, uint32_t j_out,
@@ -145,41 +153,83 @@ __device__ __forceinline__ void fir1_chunk(v2f *acc, const v2f *tpair, const v2f
     (fir1_wstep<EXACT, kFirR - 1 - Ws>(acc, tpair, base, std::make_integer_sequence<int, kFirR>{}), ...);
 }
 
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+
 template <bool EXACT>
 __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *lds = reinterpret_cast<float2 *>(smem_raw);
 
     constexpr int R = kFirR;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = (uint64_t)blockIdx.x * kFirTile;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWaves + wave) * kWaveTile;
     const uint32_t Tp = p.stage[0].ntaps_pad;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
+    float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots(Tp);
+    uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
 
-    // ---- stage the window: slot j <-> input index t0 - Tp + j ----------------
-    const uint32_t nvec = (kFirTile + Tp) >> 2;
+    // ---- load the wave's window: slot j <-> input index t0 - Tp + j ------------
+    // 1024 + Tp samples = 256 + Tp/4 vectors of 4, lane + 64*i, kept RAW in
+    // registers until the quiet test has decided whether they are needed.
+    const uint32_t nvec = (kWaveTile + Tp) >> 2;        // <= 320
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    if (aligned16 && t0 >= Tp && t0 + kFirTile <= p.n_valid) {
-        // interior tile: every sample exists, 16 B per lane
+    const bool interior = aligned16 && t0 >= Tp && t0 + kWaveTile <= p.n_valid;
+    if (interior) {
         const uint4 *src4 = reinterpret_cast<const uint4 *>(src + (t0 - Tp));
-        for (uint32_t v = tid; v < nvec; v += kFirThreads) {
-            const uint4 q = src4[v];
-            float2 *dst = lds + slot(4 * v);    // 4 slots, never straddle a pad
-            dst[0] = unpack_iq(q.x);
-            dst[1] = unpack_iq(q.y);
-            dst[2] = unpack_iq(q.z);
-            dst[3] = unpack_iq(q.w);
+        uint4 q[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t v = tid + 64u * i;
+            q[i] = (i < 4 || v < nvec) ? src4[v] : make_uint4(0, 0, 0, 0);
+        }
+        // ---- quiet test ----------------------------------------------------------
+        // |y_re|,|y_im| <= sum|h| * max|component|, so a wave whose whole window
+        // stays below quiet_lsb cannot reach the threshold: its 1024 bits are 0
+        // without running the filter -- exactly what the reference computes.
+        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].z), as_v2s(q[i].w)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].z), as_v2s(q[i].w)));
+        }
+        const int L = p.quiet_lsb;
+        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+        if (!p.fir_out && __ballot(loud) == 0) {
+            if (tid < kWaveTile / 64) words[(t0 >> 6) + tid] = 0;
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count, 1ull);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t v = tid + 64u * i;
+            if (i < 4 || v < nvec) {
+                float2 *dst = lds + slot(4 * v);        // 4 slots, never straddle a pad
+                dst[0] = unpack_iq(q[i].x);
+                dst[1] = unpack_iq(q[i].y);
+                dst[2] = unpack_iq(q[i].z);
+                dst[3] = unpack_iq(q[i].w);
+            }
         }
     } else {
-        for (uint32_t v = tid; v < nvec; v += kFirThreads) {
+        // first / last tiles of a capture, halo, unaligned host pointers
+        for (uint32_t v = tid; v < nvec; v += 64) {
             const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
             float2 *dst = lds + slot(4 * v);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = fetch_sample(p, src, nullptr, n + i);
         }
     }
-    __syncthreads();
+    // the window is private to this wavefront and the LDS executes one wave's
+    // accesses in order: no workgroup barrier, only keep the compiler from
+    // moving reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- accumulate ----------------------------------------------------------
     v2f acc[R];
@@ -274,10 +324,7 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
     // four lanes x 16 bits -> one 64-bit word
     const uint32_t pair = mask | (__shfl_xor(mask, 1) << 16);      // valid on even lanes
     const uint32_t hi = __shfl_xor(pair, 2);                       // lane+2's pair
-    if ((tid & 3u) == 0) {
-        uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-        words[(t0 >> 6) + (tid >> 2)] = (uint64_t)pair | ((uint64_t)hi << 32);
-    }
+    if ((tid & 3u) == 0) words[(t0 >> 6) + (tid >> 2)] = (uint64_t)pair | ((uint64_t)hi << 32);
 }
 
 // ---------------------------------------------------------------------------
@@ -484,8 +531,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64
 // ---------------------------------------------------------------------------
 
 static size_t fir1_lds_bytes(uint32_t Tp) {
-    const uint32_t n = kFirTile + Tp;
-    return (size_t)(n + (n >> 4) + 1) * sizeof(float2);
+    return (size_t)kFirWaves * fir1_wave_slots(Tp) * sizeof(float2);
 }
 
 static void gen_level_sizes(const FrontParams &p, uint32_t len[kMaxStages + 1]) {

@@ -14,6 +14,8 @@ constexpr int kTapChunk = 32;           // taps are padded to a multiple of this
 constexpr int kFirThreads = 256;
 constexpr int kFirR = 16;               // outputs per lane in the 1-stage kernel
 constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
+constexpr int kFirWaves = kFirThreads / 64;     // independent wavefronts per workgroup
+constexpr int kWaveTile = 64 * kFirR;           // 1024 outputs per wavefront
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
 constexpr int kBlockWords = 64;         // one edge block = 64 words = 4096 bits
 constexpr int kPayloadWords = 5;        // 4 x u64 payload + 1 spare (bit index == max_bits)
@@ -45,7 +47,9 @@ struct FrontParams {
     float *fir_out;             // optional float2 [captures][n_out]
     float p_star;               // smallest power whose sqrtf >= threshold
     float p_lo, p_hi;           // guard band (fast mode): p<p_lo => 0, p>=p_hi => 1
+    int quiet_lsb;              // all |I|,|Q| of a window below this (raw LSB) => outputs provably < threshold
     unsigned long long *recompute_count;
+    unsigned long long *quiet_count;    // waves that skipped the filter
 };
 
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,

@@ -34,6 +34,7 @@ struct ResultHeader {
     uint32_t edge_overflow;
     uint64_t totals[2];
     unsigned long long recompute;
+    unsigned long long quiet_waves;
     uint32_t total_edges;
     uint32_t scan_fallback;
 };
@@ -221,6 +222,7 @@ struct ookd_rx {
     std::vector<float> taps0;       // stage-0 true taps (guard band)
     DevBuf<float> d_taps;
     float p_star = 0, p_lo = 0, p_hi = 0;
+    int quiet_lsb = 0;              // 0 = the quiet shortcut never applies
     bool exact = false;
 
     // device (state machine)
@@ -358,6 +360,8 @@ struct ookd_rx {
         p.p_lo = p_lo;
         p.p_hi = p_hi;
         p.recompute_count = &d_hdr.p->recompute;
+        p.quiet_lsb = quiet_lsb;
+        p.quiet_count = getenv("OOKD_DEBUG") ? &d_hdr.p->quiet_waves : nullptr;
         return p;
     }
 
@@ -638,6 +642,10 @@ int ookd_rx::fetch_results() {
     stats.num_messages = 0;
     stats.num_errors = 0;
     stats.guard_recomputes = h_hdr->recompute;
+    if (getenv("OOKD_DEBUG")) {
+        fprintf(stderr, "[ookd] quiet waves skipped: %llu of %llu\n", (unsigned long long)h_hdr->quiet_waves,
+                (unsigned long long)(((run_n_out + kFirTile - 1) / kFirTile) * 4 * run_caps));
+    }
     stats.input_samples = run_n_in;
     stats.decimated_samples = run_n_out;
     stats.num_segments = run_caps * run_segs_per_cap;
@@ -762,6 +770,19 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rx->p_lo = rx->p_hi = rx->p_star;
     if (!rx->exact && rx->num_stages == 1 && rx->stage[0].decim == 1) {
         guard_band(rx->taps0, rx->p_star, rx->p_lo, rx->p_hi);
+    }
+    if (rx->num_stages == 1 && rx->stage[0].decim == 1 && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) &&
+        !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
+        // |y_re|, |y_im| <= S * m with S = sum|h|, m = max |component| in the window, so
+        // |y| <= sqrt(2) * S * m; 0.1 % slack covers every rounding of the reference's
+        // float arithmetic (relative 1e-5 at most) many times over
+        double S = 0.0;
+        for (float t : rx->taps0) S += std::fabs((double)t);
+        if (S > 0.0) {
+            // |v| < quiet_lsb  <=>  |v|/2048 < level (complexf.h:68-77 scaling)
+            const double lvl = (double)cfg->threshold * 0.999 / (1.41421356237309515 * S) * 2048.0;
+            rx->quiet_lsb = lvl >= 32767.0 ? 32767 : (int)std::ceil(lvl);
+        }
     }
 
     // ---- state machine ------------------------------------------------------------

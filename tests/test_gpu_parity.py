@@ -65,7 +65,7 @@ def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, chec
     for fsm_rounds in (False, True):
         rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
                          exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
-                         fsm_rounds=fsm_rounds)
+                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds)
         got = rx.rx(iq)
         assert got.stats["decimated_samples"] == want.decimated
         if want.decimated:
@@ -136,6 +136,27 @@ def test_g3_error_drops_rest_of_buffer(ok, oracle, vectors, spb):
     iq[2 * a:2 * b:2] = v
     got, want = _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", spb=spb)
     assert len(got.msg_samples) == vectors["G3"]["survey_num_msgs"][str(spb)]
+
+
+@pytest.mark.parametrize("thr", [0.02, 0.1, 0.5])
+def test_quiet_shortcut_boundary(ok, oracle, thr):
+    """Blocks of noise whose amplitude straddles the level below which a
+    wavefront may skip the filter: bits must not depend on the shortcut."""
+    of = _ofir(oracle, "fs32_fs4")
+    S = float(np.abs(of.taps.astype(np.float64)).sum())
+    lvl = thr * 0.999 / (np.sqrt(2.0) * S) * 2048.0      # in LSB
+    rng = np.random.default_rng(77)
+    blocks = []
+    for i in range(600):
+        amp = max(1, int(lvl * rng.choice([0.5, 0.9, 0.99, 1.0, 1.01, 1.1, 1.5, 3.0])))
+        m = int(rng.integers(300, 3000))
+        b = rng.integers(-amp, amp + 1, size=(m, 2)).astype(np.int16)
+        if rng.random() < 0.3:
+            b[:, 0] = amp            # constant: the filter's DC gain, not sum|h|, decides
+            b[:, 1] = -amp
+        blocks.append(b)
+    iq = np.concatenate(blocks).reshape(-1)
+    _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", thr=thr)
 
 
 # ----------------------------------------------- other filters / no filter ----
