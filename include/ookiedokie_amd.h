@@ -161,7 +161,10 @@ enum {
      * (sqrt(2) * sum|taps| * max|sample| < threshold) emits its 1024 zero bits
      * without running the filter -- the bits are identical, captures that are
      * mostly silence run at memory speed.  Set this to time the worst case. */
-    OOKD_RX_NO_QUIET_SKIP = 1u << 3
+    OOKD_RX_NO_QUIET_SKIP = 1u << 3,
+    /* Diagnostics: count the windows that took the shortcut (one atomic per
+     * quiet window -- slows the front end, keep out of timed runs). */
+    OOKD_RX_COUNT_QUIET = 1u << 4
 };
 
 typedef struct ookd_rx_config {
@@ -214,6 +217,10 @@ typedef struct ookd_rx_stats {
     uint32_t fsm_fallback_reason;   /* scan's refusal bits (0 = none)         */
     float fir_kernel_ms;            /* HIP-event time of the dominant kernel  */
     float total_device_ms;          /* first kernel start -> last kernel end  */
+    uint64_t quiet_waves;           /* 1024-output windows that took the quiet
+                                       shortcut (only with OOKD_RX_COUNT_QUIET) */
+    uint64_t total_waves;           /* 1024-output windows of the run (1-stage
+                                       decimation-1 front end; else 0)        */
 } ookd_rx_stats;
 
 ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
             if (tid < kWaveTile / 64) words[(t0 >> 6) + tid] = 0;
-            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count, 1ull);
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
             return;
         }
 #pragma unroll

@@ -16,6 +16,7 @@ constexpr int kFirR = 16;               // outputs per lane in the 1-stage kerne
 constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
 constexpr int kFirWaves = kFirThreads / 64;     // independent wavefronts per workgroup
 constexpr int kWaveTile = 64 * kFirR;           // 1024 outputs per wavefront
+constexpr int kQuietCounters = 1024;
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
 constexpr int kBlockWords = 64;         // one edge block = 64 words = 4096 bits
 constexpr int kPayloadWords = 5;        // 4 x u64 payload + 1 spare (bit index == max_bits)
@@ -49,7 +50,7 @@ struct FrontParams {
     float p_lo, p_hi;           // guard band (fast mode): p<p_lo => 0, p>=p_hi => 1
     int quiet_lsb;              // all |I|,|Q| of a window below this (raw LSB) => outputs provably < threshold
     unsigned long long *recompute_count;
-    unsigned long long *quiet_count;    // waves that skipped the filter
+    uint32_t *quiet_count;      // kQuietCounters spread counters of waves that skipped the filter, or null
 };
 
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,

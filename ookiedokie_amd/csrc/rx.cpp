@@ -2,6 +2,7 @@
 // demodulation entry (replaces the body of the reference loop,
 // src/ookiedokie.c:243-288, for whole captures resident in HBM).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +35,6 @@ struct ResultHeader {
     uint32_t edge_overflow;
     uint64_t totals[2];
     unsigned long long recompute;
-    unsigned long long quiet_waves;
     uint32_t total_edges;
     uint32_t scan_fallback;
 };
@@ -224,6 +224,8 @@ struct ookd_rx {
     float p_star = 0, p_lo = 0, p_hi = 0;
     int quiet_lsb = 0;              // 0 = the quiet shortcut never applies
     bool exact = false;
+    bool count_quiet = false;
+    DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics)
 
     // device (state machine)
     bool have_fsm = false;
@@ -361,7 +363,7 @@ struct ookd_rx {
         p.p_hi = p_hi;
         p.recompute_count = &d_hdr.p->recompute;
         p.quiet_lsb = quiet_lsb;
-        p.quiet_count = getenv("OOKD_DEBUG") ? &d_hdr.p->quiet_waves : nullptr;
+        p.quiet_count = count_quiet ? d_quiet.p : nullptr;
         return p;
     }
 
@@ -424,6 +426,7 @@ struct ookd_rx {
 int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                              uint32_t halo_len) {
     HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    if (count_quiet) HIPCHK(hipMemsetAsync(d_quiet.p, 0, sizeof(uint32_t) * kQuietCounters, stream));
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
@@ -568,8 +571,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.fbase = d_fbase.p;
     a.cap_base = d_cap_base.p;
     a.fin_blocks_cap = scan_fin_cap;
-    HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
-    HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+    // totals / scan_fallback are still zero from the header memset of front_and_edges
     HIPCHK(launch_fsm_scan(a, stream));
     HIPCHK(hipEventRecord(ev[2], stream));
     if (getenv("OOKD_DEBUG_SCAN")) HIPCHK(hipStreamSynchronize(stream));
@@ -642,9 +644,13 @@ int ookd_rx::fetch_results() {
     stats.num_messages = 0;
     stats.num_errors = 0;
     stats.guard_recomputes = h_hdr->recompute;
-    if (getenv("OOKD_DEBUG")) {
-        fprintf(stderr, "[ookd] quiet waves skipped: %llu of %llu\n", (unsigned long long)h_hdr->quiet_waves,
-                (unsigned long long)(((run_n_out + kFirTile - 1) / kFirTile) * 4 * run_caps));
+    if (num_stages == 1 && stage[0].decim == 1) {
+        stats.total_waves = ((run_n_out + kFirTile - 1) / kFirTile) * kFirWaves * run_caps;
+        if (count_quiet) {
+            std::vector<uint32_t> q(kQuietCounters);
+            HIPCHK(hipMemcpy(q.data(), d_quiet.p, q.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t v : q) stats.quiet_waves += v;
+        }
     }
     stats.input_samples = run_n_in;
     stats.decimated_samples = run_n_out;
@@ -852,6 +858,8 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
     rc |= rx->d_hdr.alloc(1);
+    rx->count_quiet = (cfg->flags & OOKD_RX_COUNT_QUIET) != 0;
+    if (rx->count_quiet) rc |= rx->d_quiet.alloc(kQuietCounters);
     if (rx->have_fsm) {
         rc |= rx->d_seg_bounds.alloc(caps * (rx->max_segs_per_cap + 1));
         rc |= rx->d_state_in.alloc(nseg);
@@ -927,11 +935,25 @@ int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
     rx->geometry(samples_per_capture, true, rx->run_n_in, rx->run_n_out, rx->run_words,
                  rx->run_blocks, rx->run_segs_per_cap);
     rx->stats = ookd_rx_stats{};
+    static const bool timing = getenv("OOKD_DEBUG_TIME") != nullptr;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
     if (rc != OOKD_OK) return rc;
+    const auto t1 = clk::now();
     rc = rx->run_state_machine(nullptr, true);
     if (rc != OOKD_OK) return rc;
-    return rx->fetch_results();
+    const auto t2 = clk::now();
+    rc = rx->fetch_results();
+    if (timing) {
+        const auto t3 = clk::now();
+        auto us = [](clk::time_point a, clk::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        fprintf(stderr, "[ookd] host us: enqueue front+edges %.1f, enqueue fsm %.1f, fetch (wait+copy) %.1f\n",
+                us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return rc;
 }
 
 int ookd_rx_process_host(ookd_rx *rx, const int16_t *iq, uint64_t num_samples) {
@@ -1025,6 +1047,8 @@ int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in, ookd_fsm_s
     int rc;
     if (rx->scan_used) {
         // the scan is cheap enough to simply run again from the new incoming state
+        HIPCHK(hipMemsetAsync(rx->d_hdr.p->totals, 0, sizeof(uint64_t) * 2, rx->stream));
+        HIPCHK(hipMemsetAsync(&rx->d_hdr.p->scan_fallback, 0, sizeof(uint32_t), rx->stream));
         rc = rx->run_state_machine(reinterpret_cast<const FsmStateDev *>(state_in), true);
     } else {
         rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), false, true);

@@ -49,7 +49,7 @@ def test_header_is_valid_c99(tmp_path):
 def test_struct_layouts_match_header():
     assert C.sizeof(ok.Message) == 48
     assert C.sizeof(ok.FsmState) == 64
-    assert C.sizeof(ok.RxStats) == 72
+    assert C.sizeof(ok.RxStats) == 88
 
 
 @pytest.mark.parametrize("name", ["fs32_fs4", "fs128_fs16_dec4", "unity1", "unity16"])
