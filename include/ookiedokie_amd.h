@@ -284,6 +284,57 @@ int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity,
                        uint64_t *num);
 
 /* ------------------------------------------------------------------------
+ * Host side of a decoded message: payload bits -> per-field text -> stdout
+ * text.  Replaces formatter_data_to_keyval
+ * (src/formatter.c:715-739, field rules :425-573), rx_print
+ * (src/ookiedokie.c:181-220) and, for the tx side, formatter_default_data /
+ * formatter_keyval_to_data (formatter.c:793-846).  Pure host code: a few
+ * fields per message.  The text is byte-identical to the reference's except
+ * for the optional "Decode Timestamp" value (wall clock).
+ * ---------------------------------------------------------------------- */
+typedef struct ookd_formatter ookd_formatter;
+
+enum {                              /* enum ookiedokie_rx_fmt, ookiedokie_cfg.h:41-45 */
+    OOKD_RX_FMT_PRETTY = 0,
+    OOKD_RX_FMT_CSV = 1
+};
+
+/* create_formatter (device.c:424-499) from the device's "fields" / "ts_mode". */
+ookd_formatter *ookd_formatter_create(const ookd_device *device);
+void ookd_formatter_free(ookd_formatter *f);
+uint32_t ookd_formatter_num_fields(const ookd_formatter *f);
+const char *ookd_formatter_field_name(const ookd_formatter *f, uint32_t field);
+int ookd_formatter_ts_mode(const ookd_formatter *f); /* 0 none, 1 unix, 2 unix-frac,
+                                                        3 datetime-24, 4 datetime-ampm */
+/* The value text of one field of a payload (at most 79 characters, the
+ * reference's char buf[80]). */
+int ookd_formatter_field_to_str(const ookd_formatter *f, uint32_t field,
+                                const uint8_t *payload, char *out, size_t capacity);
+/* formatter_default_data: every field's "default" deposited into payload;
+ * formatter_keyval_to_data for one (name, value) pair.  `len` = bytes at
+ * payload, at least (num_bits + 7) / 8. */
+int ookd_formatter_default_data(const ookd_formatter *f, uint8_t *payload, size_t len);
+int ookd_formatter_set_field(const ookd_formatter *f, const char *name, const char *value,
+                             uint8_t *payload, size_t len);
+
+/* What rx_print writes for ONE keyval list = the `count` messages decoded
+ * from one sdr_rx buffer (device_process appends them to the same list,
+ * device.c:634-658).  snprintf convention: returns the number of characters
+ * the full text has, stores at most capacity - 1 of them plus a NUL.
+ * *first_print (CSV heading pending) is read and cleared like the
+ * reference's flag. */
+size_t ookd_print_record(const ookd_formatter *f, int rx_fmt, int *first_print,
+                         const uint8_t *const *payloads, size_t count,
+                         char *out, size_t capacity);
+/* The whole stdout text of a run: messages grouped into records by the
+ * buffer their OUTPUT_READY sample fell into, exactly as the reference's
+ * per-buffer loop prints them (ookiedokie.c:279-286). */
+size_t ookd_print_messages(const ookd_formatter *f, int rx_fmt, int *first_print,
+                           const ookd_message *msgs, uint64_t num_messages,
+                           uint32_t samples_per_buffer, uint32_t total_decimation,
+                           char *out, size_t capacity);
+
+/* ------------------------------------------------------------------------
  * Streaming FIR with the reference's call shape: replaces
  * fir_filter_and_decimate / fir_reset (src/fir.h:68-81): history carried
  * across calls, result independent of chunking.  Host pointers in and out

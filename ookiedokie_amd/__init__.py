@@ -183,6 +183,18 @@ _PROTOTYPES = {
     "ookd_synth_fill_host": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "ookd_synth_fill_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
                                          C.c_void_p, C.c_void_p]),
+    "ookd_formatter_create": (C.c_void_p, [C.c_void_p]),
+    "ookd_formatter_free": (None, [C.c_void_p]),
+    "ookd_formatter_num_fields": (C.c_uint32, [C.c_void_p]),
+    "ookd_formatter_field_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "ookd_formatter_ts_mode": (C.c_int, [C.c_void_p]),
+    "ookd_formatter_field_to_str": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p, C.c_size_t]),
+    "ookd_formatter_default_data": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ookd_formatter_set_field": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "ookd_print_record": (C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t,
+                                       C.c_char_p, C.c_size_t]),
+    "ookd_print_messages": (C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_uint64,
+                                         C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
     "sdr_hip_file_init": (C.c_void_p, [C.c_void_p]),
     "sdr_hip_file_deinit": (None, [C.c_void_p]),
     "sdr_hip_file_rx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint]),
@@ -353,6 +365,111 @@ class Device:
 
 def device_init(path: str, sample_rate: int) -> Device:
     return Device.load(path, sample_rate)
+
+
+# --------------------------------------------------------------------------
+# formatter / printer (host side of a decoded message)
+# --------------------------------------------------------------------------
+
+RX_FMT_PRETTY = 0       # enum ookiedokie_rx_fmt, ookiedokie_cfg.h:41-45
+RX_FMT_CSV = 1
+
+
+class Formatter:
+    """struct formatter (src/formatter.h) built from a device's "fields":
+    payload bits -> per-field text -> the text rx_print writes."""
+
+    def __init__(self, device: Device):
+        h = lib().ookd_formatter_create(device._h)
+        if not h:
+            raise OokdError(-1, last_error())
+        self._h = h
+        self._payload_bytes = max(device.payload_bytes, 1)
+        self.first_print = True         # CSV heading still to be printed
+
+    @property
+    def field_names(self) -> List[str]:
+        n = lib().ookd_formatter_num_fields(self._h)
+        return [lib().ookd_formatter_field_name(self._h, i).decode() for i in range(n)]
+
+    @property
+    def ts_mode(self) -> int:
+        return int(lib().ookd_formatter_ts_mode(self._h))
+
+    def _payload(self, payload) -> np.ndarray:
+        a = np.zeros(MAX_PAYLOAD_BYTES, dtype=np.uint8)
+        p = np.frombuffer(bytes(payload), dtype=np.uint8) if not isinstance(payload, np.ndarray) else payload
+        a[:min(p.size, a.size)] = p[:a.size]
+        return a
+
+    def data_to_keyval(self, payload) -> List[Tuple[str, str]]:
+        """formatter_data_to_keyval (formatter.c:715-739), without the timestamp pair."""
+        a = self._payload(payload)
+        out = []
+        buf = C.create_string_buffer(96)
+        for i, name in enumerate(self.field_names):
+            _check(lib().ookd_formatter_field_to_str(self._h, i, a.ctypes.data, buf, len(buf)))
+            out.append((name, buf.value.decode("utf-8", "replace")))
+        return out
+
+    def default_data(self) -> np.ndarray:
+        """formatter_default_data (formatter.c:835-846)."""
+        a = np.zeros(MAX_PAYLOAD_BYTES, dtype=np.uint8)
+        _check(lib().ookd_formatter_default_data(self._h, a.ctypes.data, a.size))
+        return a[:self._payload_bytes].copy()
+
+    def keyval_to_data(self, params: Sequence[Tuple[str, str]], data: Optional[np.ndarray] = None) -> np.ndarray:
+        """formatter_keyval_to_data (formatter.c:793-832) on top of `data`
+        (default: the defaults, as device_generate does, device.c:660-676)."""
+        a = np.zeros(MAX_PAYLOAD_BYTES, dtype=np.uint8)
+        base = self.default_data() if data is None else np.asarray(data, dtype=np.uint8)
+        a[:base.size] = base
+        for k, v in params:
+            _check(lib().ookd_formatter_set_field(self._h, k.encode(), v.encode(), a.ctypes.data, a.size))
+        return a[:self._payload_bytes].copy()
+
+    def print_record(self, payloads: Sequence, fmt: int = RX_FMT_PRETTY) -> str:
+        """rx_print for the messages of ONE buffer."""
+        arrs = [self._payload(p) for p in payloads]
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        fp = C.c_int(1 if self.first_print else 0)
+        need = lib().ookd_print_record(self._h, fmt, C.byref(fp), ptrs, len(arrs), None, 0)
+        fp = C.c_int(1 if self.first_print else 0)
+        buf = C.create_string_buffer(need + 1)
+        lib().ookd_print_record(self._h, fmt, C.byref(fp), ptrs, len(arrs), buf, len(buf))
+        self.first_print = bool(fp.value)
+        return buf.value.decode("utf-8", "replace")
+
+    def print_messages(self, result: "RxResult", samples_per_buffer: int, total_decimation: int = 1,
+                       fmt: int = RX_FMT_PRETTY) -> str:
+        """Everything the reference's rx loop prints for a run's messages."""
+        n = len(result.msg_samples)
+        msgs = (Message * max(n, 1))()
+        for i in range(n):
+            msgs[i].capture = int(result.captures[i])
+            msgs[i].sample = int(result.msg_samples[i])
+            p = self._payload(result.payloads[i])
+            C.memmove(msgs[i].payload, p.ctypes.data, MAX_PAYLOAD_BYTES)
+        fp = C.c_int(1 if self.first_print else 0)
+        need = lib().ookd_print_messages(self._h, fmt, C.byref(fp), msgs, n, samples_per_buffer,
+                                         total_decimation, None, 0)
+        fp = C.c_int(1 if self.first_print else 0)
+        buf = C.create_string_buffer(need + 1)
+        lib().ookd_print_messages(self._h, fmt, C.byref(fp), msgs, n, samples_per_buffer, total_decimation,
+                                  buf, len(buf))
+        self.first_print = bool(fp.value)
+        return buf.value.decode("utf-8", "replace")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ookd_formatter_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------------

@@ -578,6 +578,11 @@ static ookd_device *device_from_json(const json::Value &root, uint32_t sample_ra
     }
     if (!load_states(*dev, *d)) return nullptr;
     if (!load_fields(*dev, *d)) return nullptr;
+    // device_init fails when create_formatter does (device.c:563-566): defaults
+    // are parsed against their field's format there
+    ookd_formatter *fmt = ookd_formatter_create(d.get());
+    if (!fmt) return nullptr;
+    ookd_formatter_free(fmt);
     if (!build_count_tables(*d)) return nullptr;
     return d.release();
 }

@@ -315,6 +315,17 @@ def ref() -> C.CDLL:
         R.ref_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         R.ref_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         R.ref_threshold.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_uint]
+        R.ref_fmt_new.restype = C.c_void_p
+        R.ref_fmt_new.argtypes = [C.c_uint, C.c_uint]
+        R.ref_fmt_free.argtypes = [C.c_void_p]
+        R.ref_fmt_add_field.argtypes = [C.c_void_p, C.c_char_p, C.c_uint, C.c_uint, C.c_int, C.c_size_t,
+                                        C.c_int, C.c_float, C.c_float]
+        R.ref_fmt_add_enum.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        R.ref_fmt_set_default.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        R.ref_fmt_initialized.argtypes = [C.c_void_p]
+        R.ref_fmt_format.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+        R.ref_fmt_default_data.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_fmt_set.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p]
         _ref = R
     return _ref
 
@@ -523,3 +534,71 @@ def ref_threshold(x: np.ndarray, thr: float) -> np.ndarray:
     out = np.empty(x.shape[0], dtype=np.uint8)
     ref().ref_threshold(x.ctypes.data, np.float32(thr), out.ctypes.data, x.shape[0])
     return out
+
+
+FMT_CODES = {"hex": 1, "unsigned decimal": 2, "sign-magnitude": 3, "two's complement": 4,
+             "float": 5, "enumeration": 6}       # formatter_fmt_value, formatter.c:859-876
+ENDIAN_CODES = {"big": 1, "little": 2}           # formatter_endianess_value, formatter.c:848-857
+
+
+class RefFormatter:
+    """The reference's real formatter (formatter.c) fed the way device.c's
+    add_field (:255-422) feeds it from a device file's "fields" entries
+    (dicts with the JSON keys).  ts_mode is always "none"."""
+
+    def __init__(self, fields, num_bits: int):
+        self.h = ref().ref_fmt_new(len(fields), num_bits)
+        if not self.h:
+            raise RuntimeError("reference formatter_init failed")
+        self.nbytes = (num_bits + 7) // 8
+        for f in fields:
+            fmt = FMT_CODES[f["format"].lower()]
+            enums = f.get("enum_values", []) if fmt == 6 else []
+            if ref().ref_fmt_add_field(self.h, f["name"].encode(), int(f["start_bit"]), int(f["end_bit"]),
+                                       fmt, len(enums), ENDIAN_CODES[f["endianness"].lower()],
+                                       float(f.get("scaling", 0.0)), float(f.get("offset", 0.0))) != 0:
+                raise ValueError("reference formatter_add_field refused %r" % f["name"])
+            for e in enums:
+                if ref().ref_fmt_add_enum(self.h, f["name"].encode(), e["string"].encode(),
+                                          int(e["value"], 0)) != 0:
+                    raise ValueError("reference formatter_add_field_enum refused %r" % e["string"])
+            if ref().ref_fmt_set_default(self.h, f["name"].encode(), f["default"].encode()) != 0:
+                raise ValueError("reference formatter_set_field_default refused %r" % f["default"])
+        if not ref().ref_fmt_initialized(self.h):
+            raise ValueError("reference formatter_initialized says no")
+
+    def data_to_keyval(self, payload):
+        a = np.zeros(max(self.nbytes, 1) + 8, dtype=np.uint8)
+        p = np.frombuffer(bytes(payload), dtype=np.uint8)
+        a[:min(p.size, self.nbytes)] = p[:self.nbytes]
+        buf = C.create_string_buffer(1 << 16)
+        if ref().ref_fmt_format(self.h, a.ctypes.data, buf, len(buf)) != 0:
+            raise RuntimeError("reference formatter_data_to_keyval failed")
+        out = []
+        for line in buf.value.decode("utf-8", "replace").split("\n"):
+            if line:
+                k, v = line.split("\t", 1)
+                out.append((k, v))
+        return out
+
+    def default_data(self) -> np.ndarray:
+        a = np.zeros(self.nbytes + 8, dtype=np.uint8)
+        ref().ref_fmt_default_data(self.h, a.ctypes.data)
+        return a[:self.nbytes].copy()
+
+    def keyval_to_data(self, params, data=None) -> np.ndarray:
+        a = np.zeros(self.nbytes + 8, dtype=np.uint8)
+        base = self.default_data() if data is None else np.asarray(data, dtype=np.uint8)
+        a[:base.size] = base
+        for k, v in params:
+            if ref().ref_fmt_set(self.h, k.encode(), v.encode(), a.ctypes.data) != 0:
+                raise ValueError("reference formatter_keyval_to_data refused %s=%s" % (k, v))
+        return a[:self.nbytes].copy()
+
+    def close(self):
+        if self.h:
+            ref().ref_fmt_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

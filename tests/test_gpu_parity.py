@@ -114,6 +114,25 @@ def test_g1_golden(ok, oracle, vectors, exact):
     assert got.stats["num_edges"] == s["num_edges"]
 
 
+def test_g1_printed_text(ok, vectors):
+    """End to end to the text the real binary printed for G1:
+    three CSV records 0x27,0xd5,2,21.500,70.700,0x00 (plus the wall-clock
+    "Decode Timestamp" column p3l-nexa2012 asks for)."""
+    g, iq = _g1(vectors)
+    f = _flt(ok, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012", RATE)
+    rx = ok.Receiver(f, d, max_samples=iq.size // 2, threshold=0.1, samples_per_buffer=8192)
+    res = rx.rx(iq)
+    fmt = ok.Formatter(d)
+    lines = fmt.print_messages(res, 8192, 1, ok.RX_FMT_CSV).split("\n")
+    assert lines[0] == "Decode Timestamp,Preamble,Unknown-1,Channel,Temperature (C),Temperature (F),Unknown-2"
+    assert [ln.split(",", 1)[1] for ln in lines[1:4]] == ["0x27,0xd5,2,21.500,70.700,0x00"] * 3
+    assert lines[4:] == [""]
+    pretty = ok.Formatter(d).print_messages(res, 8192, 1, ok.RX_FMT_PRETTY)
+    assert pretty.count("     Temperature (C) : 21.500\n") == 3 and pretty.endswith("0x00\n\n")
+    rx.close()
+
+
 @pytest.mark.parametrize("spb", [1000, 4096, 65536])
 def test_g1_other_buffer_sizes(ok, oracle, vectors, spb):
     g, iq = _g1(vectors)
