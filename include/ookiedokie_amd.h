@@ -283,6 +283,21 @@ int ookd_rx_get_fir(const ookd_rx *rx, uint32_t capture, ookd_complexf *out,
 int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity,
                        uint64_t *num);
 
+/* Recorders, by-products of a finished run:
+ *   dig : the text of `--rx-rec-dig` (record_dig, ookiedokie.c:146-169) --
+ *         "0, <level of sample 0>", then per level change at i the pair
+ *         "i-1, <old>" / "i, <new>"; snprintf convention for the in-memory
+ *         form (returns the full length);
+ *   fir : the post-filter stream as SC16Q11, what `--rx-rec` writes when
+ *         rx_rec_input is false (ookiedokie.c:265-270 through
+ *         complexf_to_sc16q11, complexf.h:87-96); needs OOKD_RX_KEEP_FIR.
+ *         (With rx_rec_input the recording is the input capture itself.) */
+size_t ookd_rx_dig_text(const ookd_rx *rx, uint32_t capture, char *out, size_t capacity);
+int ookd_rx_record_dig(const ookd_rx *rx, uint32_t capture, const char *path);
+int ookd_rx_get_fir_sc16q11(const ookd_rx *rx, uint32_t capture, int16_t *out,
+                            uint64_t capacity_samples);
+int ookd_rx_record_fir(const ookd_rx *rx, uint32_t capture, const char *path);
+
 /* ------------------------------------------------------------------------
  * Host side of a decoded message: payload bits -> per-field text -> stdout
  * text.  Replaces formatter_data_to_keyval

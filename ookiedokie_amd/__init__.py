@@ -183,6 +183,10 @@ _PROTOTYPES = {
     "ookd_synth_fill_host": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "ookd_synth_fill_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64,
                                          C.c_void_p, C.c_void_p]),
+    "ookd_rx_dig_text": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "ookd_rx_record_dig": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
+    "ookd_rx_get_fir_sc16q11": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]),
+    "ookd_rx_record_fir": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "ookd_formatter_create": (C.c_void_p, [C.c_void_p]),
     "ookd_formatter_free": (None, [C.c_void_p]),
     "ookd_formatter_num_fields": (C.c_uint32, [C.c_void_p]),
@@ -604,6 +608,29 @@ class Receiver:
         out = np.zeros((max(n, 1), 2), dtype=np.float32)
         _check(lib().ookd_rx_get_fir(self._h, capture, out.ctypes.data, n))
         return out[:n]
+
+    # -- recorders (ookiedokie.c:146-169, :265-270) -------------------------------
+    def dig_text(self, capture: int = 0) -> str:
+        """The text --rx-rec-dig would hold for this capture."""
+        need = lib().ookd_rx_dig_text(self._h, capture, None, 0)
+        if need == 0 and last_error():
+            raise OokdError(-1, last_error())
+        buf = C.create_string_buffer(need + 1)
+        lib().ookd_rx_dig_text(self._h, capture, buf, len(buf))
+        return buf.value.decode("ascii")
+
+    def record_dig(self, path: str, capture: int = 0) -> None:
+        _check(lib().ookd_rx_record_dig(self._h, capture, os.fsencode(path)))
+
+    def fir_sc16q11(self, capture: int = 0) -> np.ndarray:
+        """Post-filter samples as SC16Q11 (needs keep_fir): what --rx-rec records."""
+        n = self.stats()["decimated_samples"]
+        out = np.zeros(2 * max(n, 1), dtype=np.int16)
+        _check(lib().ookd_rx_get_fir_sc16q11(self._h, capture, out.ctypes.data, n))
+        return out[:2 * n]
+
+    def record_fir(self, path: str, capture: int = 0) -> None:
+        _check(lib().ookd_rx_record_fir(self._h, capture, os.fsencode(path)))
 
     def errors(self, cap: int = 1 << 16) -> Tuple[np.ndarray, int]:
         n = C.c_uint64(0)

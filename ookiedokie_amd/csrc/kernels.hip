@@ -487,6 +487,24 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t *iq, float2 
 }
 
 // ---------------------------------------------------------------------------
+// pack only (post-filter recorder: complexf.h:87-96 on the GPU)
+// ---------------------------------------------------------------------------
+// (int16_t)(x * 2048.0f): truncate towards zero to a 32-bit integer, keep the
+// low 16 bits (what the reference's cast compiles to on x86-64).
+__device__ __forceinline__ uint32_t pack_iq(float2 v) {
+    const int32_t re = (int32_t)(v.x * 2048.0f);
+    const int32_t im = (int32_t)(v.y * 2048.0f);
+    return ((uint32_t)re & 0xffffu) | ((uint32_t)im << 16);
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float2 *in, uint32_t *iq, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        iq[i] = pack_iq(in[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // synthetic capture generator
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64_t num_runs, uint64_t seed,
@@ -618,6 +636,15 @@ hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(unpack_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream,
                        reinterpret_cast<const uint32_t *>(iq), reinterpret_cast<float2 *>(out), n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const float *in, int16_t *iq, uint64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const float2 *>(in), reinterpret_cast<uint32_t *>(iq), n);
     return hipGetLastError();
 }
 

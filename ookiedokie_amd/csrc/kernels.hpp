@@ -208,6 +208,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 
 // ---- unpack (backend rx) ----------------------------------------------------
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream);
+// ---- pack (post-filter recorder) ----------------------------------------------
+hipError_t launch_pack(const float *in, int16_t *iq, uint64_t n, hipStream_t stream);
 
 // ---- synthetic generator ------------------------------------------------------
 

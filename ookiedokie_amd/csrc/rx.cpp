@@ -2,7 +2,9 @@
 // demodulation entry (replaces the body of the reference loop,
 // src/ookiedokie.c:243-288, for whole captures resident in HBM).
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
+#include <cinttypes>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1144,6 +1146,149 @@ int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity, 
     for (size_t s = 0; s < nseg && at < capacity; ++s) {
         const uint32_t c = std::min<uint32_t>(counts[s], rx->err_slots);
         for (uint32_t i = 0; i < c && at < capacity; ++i) samples[at++] = errs[s * rx->err_slots + i];
+    }
+    return OOKD_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// recorders
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// record_dig (ookiedokie.c:146-169) restated over the edge list: the first
+// line is sample 0's level, every later level change at i writes the pair
+// "i-1, old" / "i, new".  The edge list counts a capture that starts high as
+// a change at 0 (level before the capture = 0); record_dig does not.
+template <typename Sink>
+void dig_lines(const uint64_t *edges, uint64_t n, Sink &&sink) {
+    char line[96];
+    bool level = n > 0 && edges[0] == 0;
+    int m = snprintf(line, sizeof(line), "0, %c\n", level ? '1' : '0');
+    sink(line, (size_t)m);
+    for (uint64_t e = level ? 1 : 0; e < n; ++e) {
+        const uint64_t i = edges[e];
+        m = snprintf(line, sizeof(line), "%" PRIu64 ", %c\n%" PRIu64 ", %c\n", i - 1, level ? '1' : '0', i,
+                     level ? '0' : '1');
+        sink(line, (size_t)m);
+        level = !level;
+    }
+}
+
+int fetch_edges(const ookd_rx *rx, uint32_t capture, std::vector<uint64_t> &edges) {
+    uint64_t n = 0;
+    int rc = ookd_rx_get_edges(rx, capture, nullptr, 0, &n);
+    if (rc != OOKD_OK) return rc;
+    if (n > rx->edge_capacity) {
+        set_error("edge list overflowed its capacity: raise ookd_rx_config.edge_capacity");
+        return OOKD_ERR_CAPACITY;
+    }
+    edges.resize(n);
+    if (n) rc = ookd_rx_get_edges(rx, capture, edges.data(), n, &n);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ookd_rx_dig_text(const ookd_rx *rx, uint32_t capture, char *out, size_t capacity) {
+    clear_error();
+    if (out && capacity) out[0] = '\0';
+    if (!rx || capture >= rx->run_caps) {
+        set_error("ookd_rx_dig_text: bad argument");
+        return 0;
+    }
+    if (rx->run_n_out == 0) return 0;           // no buffer was ever processed: record_dig never ran
+    std::vector<uint64_t> edges;
+    if (fetch_edges(rx, capture, edges) != OOKD_OK) return 0;
+    size_t len = 0;
+    dig_lines(edges.data(), edges.size(), [&](const char *s, size_t m) {
+        if (out && len < capacity) memcpy(out + len, s, std::min(m, capacity - len));
+        len += m;
+    });
+    if (out && capacity) out[std::min(len, capacity - 1)] = '\0';
+    return len;
+}
+
+int ookd_rx_record_dig(const ookd_rx *rx, uint32_t capture, const char *path) {
+    clear_error();
+    if (!rx || !path || capture >= rx->run_caps) {
+        set_error("ookd_rx_record_dig: bad argument");
+        return OOKD_ERR_ARG;
+    }
+    std::vector<uint64_t> edges;
+    if (rx->run_n_out) {
+        int rc = fetch_edges(rx, capture, edges);
+        if (rc != OOKD_OK) return rc;
+    }
+    FILE *f = fopen(path, "w");                 // ookiedokie.c:112
+    if (!f) {
+        set_error("Failed to open %s: %s", path, strerror(errno));
+        return OOKD_ERR_IO;
+    }
+    bool ok = true;
+    if (rx->run_n_out) {
+        dig_lines(edges.data(), edges.size(), [&](const char *s, size_t m) { ok = ok && fwrite(s, 1, m, f) == m; });
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        set_error("Failed to write %s", path);
+        return OOKD_ERR_IO;
+    }
+    return OOKD_OK;
+}
+
+int ookd_rx_get_fir_sc16q11(const ookd_rx *rx, uint32_t capture, int16_t *out, uint64_t capacity) {
+    clear_error();
+    if (!rx || !out || capture >= rx->run_caps) return OOKD_ERR_ARG;
+    if (!rx->d_fir.p) {
+        set_error("ookd_rx_get_fir_sc16q11 needs OOKD_RX_KEEP_FIR");
+        return OOKD_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(rx->dev));
+    const uint64_t n = std::min<uint64_t>(capacity, rx->run_n_out);
+    if (n == 0) return OOKD_OK;
+    int16_t *d_tmp = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_tmp), n * 4));
+    hipError_t e = launch_pack(rx->d_fir.p + 2 * (size_t)capture * rx->run_n_out, d_tmp, n, rx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, n * 4, hipMemcpyDeviceToHost, rx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(rx->stream);
+    (void)hipFree(d_tmp);
+    if (e != hipSuccess) {
+        set_error("ookd_rx_get_fir_sc16q11: %s", hipGetErrorString(e));
+        return OOKD_ERR_HIP;
+    }
+    return OOKD_OK;
+}
+
+int ookd_rx_record_fir(const ookd_rx *rx, uint32_t capture, const char *path) {
+    clear_error();
+    if (!rx || !path || capture >= rx->run_caps) {
+        set_error("ookd_rx_record_fir: bad argument");
+        return OOKD_ERR_ARG;
+    }
+    if (!rx->d_fir.p) {
+        set_error("ookd_rx_record_fir needs OOKD_RX_KEEP_FIR");
+        return OOKD_ERR_ARG;
+    }
+    std::vector<int16_t> buf(2 * rx->run_n_out);
+    if (rx->run_n_out) {
+        int rc = ookd_rx_get_fir_sc16q11(rx, capture, buf.data(), rx->run_n_out);
+        if (rc != OOKD_OK) return rc;
+    }
+    FILE *f = fopen(path, "wb");                // bladeRF_file.c:82 (tx direction)
+    if (!f) {
+        set_error("Failed to open %s: %s", path, strerror(errno));
+        return OOKD_ERR_IO;
+    }
+    bool ok = fwrite(buf.data(), 4, rx->run_n_out, f) == rx->run_n_out;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        set_error("Failed to write %s", path);
+        return OOKD_ERR_IO;
     }
     return OOKD_OK;
 }

@@ -357,6 +357,36 @@ def unpack(iq: np.ndarray) -> np.ndarray:
     return out
 
 
+def pack(x: np.ndarray) -> np.ndarray:
+    """complexf_to_sc16q11 (complexf.h:87-96)."""
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2)
+    out = np.empty(2 * x.shape[0], dtype=np.int16)
+    lib().ook_pack(x.ctypes.data, out.ctypes.data, x.shape[0])
+    return out
+
+
+def dig_text(bits: np.ndarray, buffer_len: int = 8192) -> str:
+    """record_dig (ookiedokie.c:146-169) as written: per buffer, per sample,
+    with its `prev` / `sample_no` carried across buffers.  Small inputs only."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    out = []
+    sample_no = 0
+    prev = 0
+    for start in range(0, bits.size, buffer_len):
+        buf = bits[start:start + buffer_len]
+        if sample_no == 0:                                   # :150-153
+            prev = int(buf[0])
+            out.append("0, %c\n" % ("1" if buf[0] else "0"))
+        idx = np.nonzero(np.diff(np.concatenate(([prev], buf))))[0]
+        for i in idx:                                        # :155-166
+            cur = int(buf[i])
+            out.append("%d, %c\n%d, %c\n" % (sample_no + i - 1, "1" if prev else "0",
+                                              sample_no + i, "1" if cur else "0"))
+            prev = cur
+        sample_no += buf.size
+    return "".join(out)
+
+
 def threshold(x: np.ndarray, thr: float) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 2)
     out = np.empty(x.shape[0], dtype=np.uint8)

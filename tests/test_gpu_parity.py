@@ -178,6 +178,59 @@ def test_quiet_shortcut_boundary(ok, oracle, thr):
     _compare(ok, oracle, iq, "fs32_fs4", "p3l-nexa2012", thr=thr)
 
 
+# ----------------------------------------------------------------- recorders ----
+
+def test_rx_rec_dig_text(ok, oracle, vectors, tmp_path):
+    """--rx-rec-dig (ookiedokie.c:146-169): text identical to record_dig run
+    over the oracle's bit stream; first edges as the real binary wrote them
+    for G1."""
+    g, iq = _g1(vectors)
+    f = _flt(ok, "fs32_fs4")
+    rx = ok.Receiver(f, None, max_samples=iq.size // 2, threshold=0.1, samples_per_buffer=8192)
+    rx.rx(iq)
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, None, 8192, want_bits=True)
+    text = rx.dig_text()
+    assert text == oracle.dig_text(want.bits, 8192)
+    assert text.startswith("0, 0\n12013, 0\n12014, 1\n13516, 1\n13517, 0\n39613, 0\n39614, 1\n")
+    assert text.count("\n") == 1 + 2 * 228
+    p = tmp_path / "dig.csv"
+    rx.record_dig(str(p))
+    assert p.read_text() == text
+    rx.close()
+    # a capture that starts high: first line carries the level, no pair for sample 0
+    iq2 = np.zeros(2 * 5000, dtype=np.int16)
+    iq2[0:2 * 1200:2] = 1945
+    iq2[2 * 3000:2 * 3100:2] = 1945
+    rx = ok.Receiver(None, None, max_samples=5000, threshold=0.1, samples_per_buffer=1000)
+    rx.rx(iq2)
+    want = oracle.rx(iq2, None, 0.1, None, 1000, want_bits=True)
+    assert rx.dig_text() == oracle.dig_text(want.bits, 1000) == (
+        "0, 1\n1199, 1\n1200, 0\n2999, 0\n3000, 1\n3099, 1\n3100, 0\n")
+    rx.rx(np.zeros(0, dtype=np.int16))
+    assert rx.dig_text() == ""                 # no buffer, no first line
+    rx.close()
+
+
+@pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
+def test_rx_rec_post_filter_sc16q11(ok, oracle, vectors, tmp_path, filt):
+    """--rx-rec (post-filter, ookiedokie.c:265-270): complexf_to_sc16q11 of the
+    filter output, checked against the oracle's pack and the reference's own
+    complexf.h through oracle/_ref."""
+    g, iq = _g1(vectors, noise_seed=21)
+    iq = iq[:2 * 300000]
+    f = _flt(ok, filt)
+    rx = ok.Receiver(f, None, max_samples=iq.size // 2, threshold=0.1, samples_per_buffer=8192,
+                     exact_fir=True, keep_fir=True)
+    rx.rx(iq)
+    want = oracle.rx(iq, _ofir(oracle, filt), 0.1, None, 8192, want_fir=True)
+    got = rx.fir_sc16q11()
+    assert (got == oracle.pack(want.fir)).all()
+    p = tmp_path / "post.sc16q11"
+    rx.record_fir(str(p))
+    assert (np.fromfile(str(p), dtype=np.int16) == got).all()
+    rx.close()
+
+
 # ----------------------------------------------- other filters / no filter ----
 
 @pytest.mark.parametrize("filt", ["fs128_fs16_dec4", "unity16", "unity1", None])
