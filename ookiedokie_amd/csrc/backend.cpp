@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include "ingest.hpp"
 #include "kernels.hpp"
 
 using namespace ookd;
@@ -34,6 +35,7 @@ struct HipFile {
     int16_t *d_capture = nullptr;
     uint64_t capture_samples = 0;
     std::string path;
+    Ingest ingest;
 
     ~HipFile() {
         if (file) fclose(file);
@@ -153,19 +155,13 @@ int sdr_hip_file_capture(void *handle, const void **d_iq, uint64_t *num_samples)
             set_error("hip_file: capture allocation of %llu bytes failed", (unsigned long long)n * 4);
             return OOKD_ERR_NOMEM;
         }
-        // stream through the pinned block buffer
-        uint64_t done = 0;
-        while (done < n) {
-            const size_t want = (size_t)std::min<uint64_t>(h->buf_len, n - done);
-            const size_t got = fread(h->h_raw, 4, want, f);
-            if (got == 0) break;
-            if (hipMemcpy(h->d_capture + 2 * done, h->h_raw, got * 4, hipMemcpyHostToDevice) != hipSuccess) {
-                fclose(f);
-                set_error("hip_file: H2D copy failed");
-                return OOKD_ERR_HIP;
-            }
-            done += got;
+        // pinned double-buffered ingest: fread of block k+1 overlaps the DMA of block k
+        const long long got = h->ingest.from_file(f, h->d_capture, n * 4);
+        if (got < 0) {
+            fclose(f);
+            return OOKD_ERR_HIP;
         }
+        const uint64_t done = (uint64_t)got / 4;
         fclose(f);
         h->capture_samples = done;
     }

@@ -11,6 +11,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include "ingest.hpp"
 #include "kernels.hpp"
 
 using namespace ookd;
@@ -276,6 +277,7 @@ struct ookd_rx {
     DevBuf<unsigned long long> d_cap_base;
     uint32_t scan_fin_cap = 0;
     DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
+    Ingest ingest;                  // its pinned double buffer (lazy)
 
     ResultHeader *h_hdr = nullptr;  // pinned
     MsgDev *h_msgs = nullptr;       // pinned, msg_capacity
@@ -974,9 +976,7 @@ int ookd_rx_process_host(ookd_rx *rx, const int16_t *iq, uint64_t num_samples) {
         int rc = rx->d_stage_in.alloc(2 * rx->max_samples + 8);
         if (rc != OOKD_OK) return rc;
     }
-    if (num_samples) {
-        HIPCHK(hipMemcpyAsync(rx->d_stage_in.p, iq, num_samples * 4, hipMemcpyHostToDevice, rx->stream));
-    }
+    if (num_samples && rx->ingest.from_host(iq, rx->d_stage_in.p, num_samples * 4) < 0) return OOKD_ERR_HIP;
     return ookd_rx_process_device(rx, rx->d_stage_in.p, 1, num_samples, num_samples);
 }
 
