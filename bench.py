@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true", help="unfused reference-order FIR everywhere")
+    ap.add_argument("--filter", default="fs32_fs4", help=argparse.SUPPRESS)   # experiments only
     ap.add_argument("--no-quiet-skip", action="store_true",
                     help="filter every window, even those provably below the threshold (worst case)")
     args = ap.parse_args()
@@ -78,7 +79,7 @@ def main():
 
     ok.lib()
     n = args.samples
-    flt = ok.Filter.load(golden("filters", "fs32_fs4"))
+    flt = ok.Filter.load(golden("filters", args.filter))
     dev = ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // flt.total_decimation)
 
     # ---- synthetic capture generated directly in HBM ----------------------------------
@@ -152,7 +153,7 @@ def main():
             "config": {
                 "workload": "configs[1]: 1 GiB synthetic SC16Q11 capture per GPU, fs32_fs4 FIR, "
                             "p3l-nexa2012 state machine",
-                "samples_per_capture": n, "captures_per_gpu": 1, "filter": "fs32_fs4",
+                "samples_per_capture": n, "captures_per_gpu": 1, "filter": args.filter,
                 "device": "p3l-nexa2012", "sample_rate": RATE, "threshold": THRESHOLD,
                 "samples_per_buffer": SPB, "fir_mode": "exact" if args.exact else "fma+guard-band",
                 "parallelism": "independent captures per rank, no collective",
@@ -187,8 +188,8 @@ def main():
         O.build()
         m = min(CPU_SLICE, n)
         iq = capture[:2 * m].cpu().numpy()
-        ofir = O.load_filter_json(golden("filters", "fs32_fs4"))
-        odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE)
+        ofir = O.load_filter_json(golden("filters", args.filter))
+        odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE // flt.total_decimation)
         t1 = time.perf_counter()
         want = O.rx(iq, ofir, THRESHOLD, odev, SPB)
         cpu_s = time.perf_counter() - t1

@@ -15,6 +15,7 @@
 // multiply-adds are written explicitly with __builtin_fmaf.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <utility>
 
 #pragma clang fp contract(off)
@@ -50,6 +51,17 @@ __device__ __forceinline__ float2 fetch_sample(const FrontParams &p, const uint3
     if ((uint64_t)n >= p.n_valid) return make_float2(0.0f, 0.0f);
     if (srcf) return srcf[n];
     return unpack_iq(src[n]);
+}
+
+// Same for int16 inputs, returned raw (packed I | Q << 16).
+__device__ __forceinline__ uint32_t fetch_raw(const FrontParams &p, const uint32_t *src, int64_t n) {
+    if (n < 0) {
+        const int64_t h = (int64_t)p.halo_len + n;
+        if (h < 0 || !p.halo) return 0u;
+        return reinterpret_cast<const uint32_t *>(p.halo)[h];
+    }
+    if ((uint64_t)n >= p.n_valid) return 0u;
+    return src[n];
 }
 
 // ookiedokie.c:171-179: bit = sqrtf(re*re + im*im) >= thr.  sqrtf is
@@ -328,6 +340,253 @@ __global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParam
 }
 
 // ---------------------------------------------------------------------------
+// front end, two decimating stages (the backend default fs128_fs16_dec4:
+// 16 taps / 2 then 32 taps / 2) -- SURVEY.md 8(f) row f1
+// ---------------------------------------------------------------------------
+//
+// Same execution model as the 1-stage kernel: one wavefront = one tile, no
+// workgroup barrier, raw loads -> quiet test -> unpack into a private LDS
+// window -> register-blocked packed MACs with the taps in SGPRs.  Here the
+// tile is F = 64*R2 final outputs; stage 1 first produces the L1 intermediate
+// outputs stage 2 needs (its own halo recomputed per tile, ~12 %) into a
+// second LDS window.  Stage output J reads inputs D*(J+1)-1-k (fir.c:290:
+// the countdown starts at D); every stage's geometry is a compile-time
+// constant, so all LDS addresses in the MAC bodies are lane_base + immediate.
+//
+// Arithmetic is always the reference's (separately rounded multiply and
+// add): floats and bits are bit-identical, no guard band needed.
+//
+// LDS layout per level: lane t's block of P = D*R consecutive samples starts
+// at slot t*(P+1) -- one pad per block makes the lane stride odd, i.e.
+// conflict free for ds_read_b64.
+
+template <int D1_, int N1_, int D2_, int N2_, int R2_>
+struct Fir2Geom {
+    static constexpr int D1 = D1_, D2 = D2_, R2 = R2_;
+    static constexpr int T1 = 16 * N1_, T2 = 16 * N2_;         // padded tap counts
+    static constexpr int N1 = N1_, N2 = N2_;
+    static constexpr int F = 64 * R2;                           // final outputs per wave
+    static constexpr int L1need = D2 * (F - 1) + T2;            // stage-1 outputs stage 2 reads
+    static constexpr int R1 = (L1need + 63) / 64;
+    static constexpr int L1 = 64 * R1;                          // stage-1 outputs computed
+    static constexpr int L0 = D1 * (L1 - 1) + T1;               // input samples read
+    static constexpr int P1 = D1 * R1, P2 = D2 * R2;
+    static constexpr int kVecs = (L0 + 3 + 3) / 4;              // 16 B loads (the window may start mid-vector)
+    static constexpr int kVecRounds = (kVecs + 63) / 64;
+    static constexpr int slots0 = (L0 + L0 / P1 + 2 + 1) & ~1;  // level 0 stays RAW: 4 B per sample
+    static constexpr int slots1 = L1 + L1 / P2 + 2;             // level 1: float2
+    static constexpr int wave_bytes = ((slots0 * 4 + slots1 * 8) + 15) & ~15;
+};
+
+// One 16-tap chunk of a decimating stage: window position W (newest first)
+// feeds output r with tap kk = D*r - D*(R-1) + W when 0 <= kk < 16.
+__device__ __forceinline__ v2f lds_sample(const v2f *base, int i) { return base[i]; }
+__device__ __forceinline__ v2f lds_sample(const uint32_t *base, int i) {       // raw SC16Q11 level
+    const float2 v = unpack_iq(base[i]);
+    return (v2f){v.x, v.y};
+}
+
+template <bool EXACT, int D, int R, int P, int CHUNK_OFF, int W, typename In, int... Rs>
+__device__ __forceinline__ void fir2_wstep(v2f *acc, const v2f *tpair, const In *base,
+                                           std::integer_sequence<int, Rs...>) {
+    // sample index inside the lane's window: c = Tpad-1 + D*(R-1) - 16*chunk - W
+    constexpr int c = CHUNK_OFF + D * (R - 1) - W;
+    static_assert(c >= 0, "window underflow");
+    const v2f x = lds_sample(base, c + c / P);
+    ((void)((D * Rs - D * (R - 1) + W >= 0 && D * Rs - D * (R - 1) + W < 16)
+                ? (cmac<EXACT, ((D * Rs - D * (R - 1) + W) & 1) != 0>(
+                       acc[Rs], tpair[((D * Rs - D * (R - 1) + W) & 15) >> 1], x),
+                   0)
+                : 0),
+     ...);
+}
+
+template <bool EXACT, int D, int R, int P, int CHUNK_OFF, typename In, int... Ws>
+__device__ __forceinline__ void fir2_chunk_body(v2f *acc, const v2f *tpair, const In *base,
+                                                std::integer_sequence<int, Ws...>) {
+    (fir2_wstep<EXACT, D, R, P, CHUNK_OFF, Ws>(acc, tpair, base, std::make_integer_sequence<int, R>{}), ...);
+}
+
+// All chunks of one stage, taps kk ascending across chunks (reference order).
+template <bool EXACT, int D, int R, int P, int TPAD, int CH, typename In>
+__device__ __forceinline__ void fir2_stage_chunk(v2f *acc, const float *taps, const In *base) {
+    v8f ta, tb;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\t"
+                 "s_load_dwordx8 %1, %2, 0x20\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(ta), "=&s"(tb)
+                 : "s"(taps + 16 * CH)
+                 : "memory");
+    const v2f tpair[8] = {
+        __builtin_shufflevector(ta, ta, 0, 1), __builtin_shufflevector(ta, ta, 2, 3),
+        __builtin_shufflevector(ta, ta, 4, 5), __builtin_shufflevector(ta, ta, 6, 7),
+        __builtin_shufflevector(tb, tb, 0, 1), __builtin_shufflevector(tb, tb, 2, 3),
+        __builtin_shufflevector(tb, tb, 4, 5), __builtin_shufflevector(tb, tb, 6, 7)};
+    // tap k = 16*CH + kk of output r reads window sample (TPAD-1) + D*r - k
+    fir2_chunk_body<EXACT, D, R, P, TPAD - 1 - 16 * CH>(acc, tpair, base,
+                                                 std::make_integer_sequence<int, D*(R - 1) + 16>{});
+}
+
+template <bool EXACT, int D, int R, int P, int TPAD, typename In, int... CHs>
+__device__ __forceinline__ void fir2_stage(v2f *acc, const float *taps, const In *base,
+                                           std::integer_sequence<int, CHs...>) {
+    (fir2_stage_chunk<EXACT, D, R, P, TPAD, CHs>(acc, taps, base), ...);
+}
+
+// Reference-order recomputation of one final output (guard-band path): the
+// T2 stage-1 outputs it reads, each from the raw level-0 window, then stage 2.
+// `j` = final output index inside the tile.
+template <typename G>
+__device__ __noinline__ float2 fir2_exact_output(const uint32_t *lds0, const float *taps1, uint32_t ntaps1,
+                                                 const float *taps2, uint32_t ntaps2, uint32_t j) {
+    float re2 = 0.0f, im2 = 0.0f;
+    for (uint32_t k2 = 0; k2 < ntaps2; ++k2) {
+        const uint32_t j1 = G::D2 * j + (G::T2 - 1) - k2;               // local stage-1 index
+        float re1 = 0.0f, im1 = 0.0f;
+        for (uint32_t k1 = 0; k1 < ntaps1; ++k1) {
+            const uint32_t i = G::D1 * j1 + (G::T1 - 1) - k1;           // local input index
+            const float2 x = unpack_iq(lds0[i + i / G::P1]);
+            const float t = taps1[k1];
+            const float pr = t * x.x;
+            const float pi = t * x.y;
+            re1 = re1 + pr;
+            im1 = im1 + pi;
+        }
+        const float t2 = taps2[k2];
+        const float pr = t2 * re1;
+        const float pi = t2 * im1;
+        re2 = re2 + pr;
+        im2 = im2 + pi;
+    }
+    return make_float2(re2, im2);
+}
+
+constexpr int kFir2Waves = 2;           // ~10 KiB of LDS per wave: 2-wave workgroups pack 14 waves / CU
+
+template <typename G, bool EXACT>
+__global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t tid = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t cap = blockIdx.y;
+    const uint64_t J0 = ((uint64_t)blockIdx.x * kFir2Waves + wave) * G::F;     // first final output
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
+    uint32_t *lds0 = reinterpret_cast<uint32_t *>(smem_raw + wave * G::wave_bytes);    // raw I,Q pairs
+    float2 *lds1 = reinterpret_cast<float2 *>(lds0 + G::slots0);
+    uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+
+    // global index of local stage-1 output 0 and of local input sample 0
+    const int64_t j1_0 = (int64_t)G::D2 * (int64_t)J0 + (G::D2 - 1) - (G::T2 - 1);
+    const int64_t a0 = (int64_t)G::D1 * j1_0 + (G::D1 - 1) - (G::T1 - 1);
+
+    // ---- load + quiet test + unpack (as in fir1_bits_kernel) ---------------------
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const int64_t va = a0 & ~(int64_t)3;
+    const bool interior = aligned16 && a0 >= 0 && (uint64_t)(va + 4 * G::kVecs) <= p.n_valid;
+    if (interior) {
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src + va);
+        uint4 q[G::kVecRounds];
+#pragma unroll
+        for (int i = 0; i < G::kVecRounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            q[i] = (64 * (i + 1) <= G::kVecs || v < (uint32_t)G::kVecs) ? src4[v] : make_uint4(0, 0, 0, 0);
+        }
+        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+#pragma unroll
+        for (int i = 0; i < G::kVecRounds; ++i) {
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].z), as_v2s(q[i].w)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].z), as_v2s(q[i].w)));
+        }
+        const int L = p.quiet_lsb;
+        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+        if (!p.fir_out && __ballot(loud) == 0) {
+            if (tid < G::F / 64) words[(J0 >> 6) + tid] = 0;
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
+            return;
+        }
+        const int shift = (int)(a0 - va);           // 0..3 samples of the first vector precede the window
+#pragma unroll
+        for (int i = 0; i < G::kVecRounds; ++i) {
+            const int i0 = 4 * (int)(tid + 64u * i) - shift;        // local index of q[i].x
+            const uint32_t w4[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int li = i0 + e;
+                if (li >= 0 && li < G::L0) lds0[li + li / G::P1] = w4[e];
+            }
+        }
+    } else {
+        // first / last tiles, halo: values outside the capture are zeros or the
+        // previous shard's samples -- all of them int16, so the level stays raw
+        for (int li = (int)tid; li < G::L0; li += 64) {
+            lds0[li + li / G::P1] = fetch_raw(p, src, a0 + li);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 1: lane t -> local outputs R1*t .. R1*t + R1-1 ---------------------------
+    {
+        v2f acc[G::R1];
+#pragma unroll
+        for (int r = 0; r < G::R1; ++r) acc[r] = (v2f){0.0f, 0.0f};
+        const uint32_t *base = lds0 + (G::P1 + 1) * tid;
+        fir2_stage<EXACT, G::D1, G::R1, G::P1, G::T1>(acc, p.taps + p.stage[0].tap_off, base,
+                                               std::make_integer_sequence<int, G::N1>{});
+#pragma unroll
+        for (int r = 0; r < G::R1; ++r) {
+            const int j = G::R1 * (int)tid + r;
+            lds1[j + j / G::P2] = make_float2(acc[r].x, acc[r].y);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 2: lane t -> final outputs J0 + R2*t .. + R2-1 ------------------------------
+    v2f acc[G::R2];
+#pragma unroll
+    for (int r = 0; r < G::R2; ++r) acc[r] = (v2f){0.0f, 0.0f};
+    {
+        const v2f *base = reinterpret_cast<const v2f *>(lds1 + (G::P2 + 1) * tid);
+        fir2_stage<EXACT, G::D2, G::R2, G::P2, G::T2>(acc, p.taps + p.stage[1].tap_off, base,
+                                               std::make_integer_sequence<int, G::N2>{});
+    }
+
+    // ---- threshold + pack: R2 bits per lane, 64 / R2 lanes per word ----------------------------
+    static_assert(G::R2 == 4, "bit packing below assumes 4 outputs per lane");
+    const uint64_t o0 = J0 + (uint64_t)tid * G::R2;
+    uint32_t nib = 0;
+    float2 *fout = p.fir_out ? reinterpret_cast<float2 *>(p.fir_out) + (uint64_t)cap * p.n_out : nullptr;
+#pragma unroll
+    for (int r = 0; r < G::R2; ++r) {
+        const bool valid = o0 + r < p.n_out;
+        const float pw = power_ref(acc[r].x, acc[r].y);
+        bool bit = pw >= (EXACT ? p.p_star : p.p_hi);
+        if (!EXACT && valid && !bit && pw >= p.p_lo) {
+            // inside the guard band: redo this output in the reference's exact order
+            const float2 y = fir2_exact_output<G>(lds0, p.taps + p.stage[0].tap_off, p.stage[0].ntaps,
+                                                  p.taps + p.stage[1].tap_off, p.stage[1].ntaps, G::R2 * tid + r);
+            bit = power_ref(y.x, y.y) >= p.p_star;
+            if (p.recompute_count) atomicAdd(p.recompute_count, 1ull);
+        }
+        nib |= ((valid && bit) ? 1u : 0u) << r;
+        if (fout && valid) fout[o0 + r] = make_float2(acc[r].x, acc[r].y);
+    }
+    uint32_t half = nib << (4u * (tid & 7u));
+    half |= __shfl_xor(half, 1);
+    half |= __shfl_xor(half, 2);
+    half |= __shfl_xor(half, 4);                // lanes 8g..8g+7 hold outputs 32g..32g+31
+    const uint32_t hi = __shfl_down(half, 8);
+    if ((tid & 15u) == 0) words[(J0 >> 6) + (tid >> 4)] = (uint64_t)half | ((uint64_t)hi << 32);
+}
+
+typedef Fir2Geom<2, 1, 2, 2, 4> Fir2Dec4;      // fs128_fs16_dec4: (D 2, 16 taps), (D 2, 32 taps)
+
+// ---------------------------------------------------------------------------
 // front end, generic: any number of stages / decimations, exact arithmetic
 // ---------------------------------------------------------------------------
 //
@@ -598,6 +857,26 @@ hipError_t launch_front_generic(const FrontParams &p, uint32_t num_captures, hip
     return hipGetLastError();
 }
 
+static bool use_fir1(const FrontParams &p) {
+    return p.num_stages == 1 && p.stage[0].decim == 1 && p.origin == 0 && !p.iq_f32 &&
+           fir1_lds_bytes(p.stage[0].ntaps_pad) <= 160 * 1024;
+}
+
+static bool use_fir2(const FrontParams &p) {
+    // every level's phase is D-1 when the origin is a multiple of the total decimation
+    return p.num_stages == 2 && !p.iq_f32 && !p.halo_f32 && p.stage[0].decim == 2 && p.stage[1].decim == 2 &&
+           p.stage[0].ntaps <= Fir2Dec4::T1 && p.stage[1].ntaps <= Fir2Dec4::T2 && p.origin % 4 == 0;
+}
+
+uint64_t front_wave_tiles(const FrontParams &p) {
+    if (use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * kFirWaves;
+    if (use_fir2(p)) {
+        const uint64_t per_wg = (uint64_t)kFir2Waves * Fir2Dec4::F;
+        return ((p.n_out + per_wg - 1) / per_wg) * kFir2Waves;
+    }
+    return 0;
+}
+
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream) {
     if (p.n_out == 0) return hipSuccess;
     if (p.num_stages == 0) {
@@ -607,9 +886,9 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         hipLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)blocks, num_captures), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
-    if (p.num_stages == 1 && p.stage[0].decim == 1 && p.origin == 0 && !p.iq_f32) {
+    if (use_fir1(p)) {
         const size_t lds = fir1_lds_bytes(p.stage[0].ntaps_pad);
-        if (lds <= 160 * 1024) {
+        {
             const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile;
             dim3 grid((uint32_t)tiles, num_captures);
             hipError_t e;
@@ -626,6 +905,17 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
             }
             return hipGetLastError();
         }
+    }
+    if (use_fir2(p)) {
+        const size_t lds = (size_t)kFir2Waves * Fir2Dec4::wave_bytes;
+        const uint64_t tiles = (p.n_out + (uint64_t)kFir2Waves * Fir2Dec4::F - 1) / ((uint64_t)kFir2Waves * Fir2Dec4::F);
+        const dim3 grid((uint32_t)tiles, num_captures), block(64 * kFir2Waves);
+        if (exact) {
+            hipLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, true>), grid, block, lds, stream, p);
+        } else {
+            hipLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, false>), grid, block, lds, stream, p);
+        }
+        return hipGetLastError();
     }
     return launch_front_generic(p, num_captures, stream);
 }

@@ -55,6 +55,9 @@ struct FrontParams {
 
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
                         hipStream_t stream);
+// 1024-ish output windows ("wave tiles") the tuned kernels split a capture into
+// (0 when the generic kernel serves this shape).
+uint64_t front_wave_tiles(const FrontParams &p);
 // Generic multi-stage kernel regardless of shape (cross-check / streaming FIR).
 hipError_t launch_front_generic(const FrontParams &p, uint32_t num_captures,
                                 hipStream_t stream);

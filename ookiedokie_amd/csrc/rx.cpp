@@ -80,16 +80,26 @@ float power_threshold(float thr) {
 // e bounds |y_fma - y_ref| per component: both chains are within
 // gamma_T * sum|h||x| of the exact sum (one rounding per step for fma, two
 // for mul+add), inputs are bounded by 32768/2048 = 16.
-void guard_band(const std::vector<float> &taps, float p_star, float &p_lo, float &p_hi) {
+//
+// Several stages: the fused and the reference chain of stage s+1 start from
+// inputs that already differ by e_s, which the stage amplifies by at most
+// sum|h_{s+1}|, and add their own rounding difference on values bounded by
+// 16 * prod sum|h|:  e = 2.2 u * 16 * prod_s S_s * sum_s (T_s + 1).
+void guard_band(const std::vector<std::vector<float>> &stages, float p_star, float &p_lo, float &p_hi) {
     if (std::isnan(p_star) || std::isinf(p_star) || p_star <= 0.0f) {
         p_lo = p_hi = p_star;
         return;
     }
     const double u = std::ldexp(1.0, -24);
-    double S = 0.0;
-    for (float t : taps) S += std::fabs((double)t);
-    const double T = (double)taps.size();
-    const double e = 2.2 * (T + 1.0) * u * S * 16.0 + T * std::ldexp(1.0, -140);
+    double S = 1.0, T = 0.0, Tsum = 0.0;
+    for (const auto &taps : stages) {
+        double ss = 0.0;
+        for (float t : taps) ss += std::fabs((double)t);
+        S *= std::max(ss, 1.0);         // a stage with gain < 1 still adds its own roundings
+        T += (double)taps.size() + 1.0;
+        Tsum += (double)taps.size();
+    }
+    const double e = 2.2 * T * u * S * 16.0 * (stages.size() > 1 ? 1.01 : 1.0) + Tsum * std::ldexp(1.0, -140);
     const double P = (double)p_star;
     // |p_ref - p_fma| <= m(p) = 3.003*e*sqrt(p) + 3e^2 + 6u*p
     // upper edge: smallest s = sqrt(p) with (1-6u)s^2 - 3.003e s - (3e^2 + P) >= 0
@@ -648,8 +658,8 @@ int ookd_rx::fetch_results() {
     stats.num_messages = 0;
     stats.num_errors = 0;
     stats.guard_recomputes = h_hdr->recompute;
-    if (num_stages == 1 && stage[0].decim == 1) {
-        stats.total_waves = ((run_n_out + kFirTile - 1) / kFirTile) * kFirWaves * run_caps;
+    stats.total_waves = front_wave_tiles(front_params(nullptr, 0)) * run_caps;
+    if (stats.total_waves) {
         if (count_quiet) {
             std::vector<uint32_t> q(kQuietCounters);
             HIPCHK(hipMemcpy(q.data(), d_quiet.p, q.size() * 4, hipMemcpyDeviceToHost));
@@ -778,16 +788,23 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     }
     rx->p_star = power_threshold(cfg->threshold);
     rx->p_lo = rx->p_hi = rx->p_star;
-    if (!rx->exact && rx->num_stages == 1 && rx->stage[0].decim == 1) {
-        guard_band(rx->taps0, rx->p_star, rx->p_lo, rx->p_hi);
+    if (!rx->exact && filter) {
+        // used by the tuned kernels (1 stage / decimation 1, and 2 x decimation 2); the
+        // generic kernel always computes in reference order and ignores the band
+        std::vector<std::vector<float>> st;
+        for (const auto &f : filter->stages) st.push_back(f.taps);
+        guard_band(st, rx->p_star, rx->p_lo, rx->p_hi);
     }
-    if (rx->num_stages == 1 && rx->stage[0].decim == 1 && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) &&
-        !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
-        // |y_re|, |y_im| <= S * m with S = sum|h|, m = max |component| in the window, so
-        // |y| <= sqrt(2) * S * m; 0.1 % slack covers every rounding of the reference's
-        // float arithmetic (relative 1e-5 at most) many times over
-        double S = 0.0;
-        for (float t : rx->taps0) S += std::fabs((double)t);
+    if (filter && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) && !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
+        // |y_re|, |y_im| <= S * m with S = prod over stages of sum|h|, m = max |component| in
+        // the window, so |y| <= sqrt(2) * S * m; 0.1 % slack covers every rounding of the
+        // reference's float arithmetic (relative 1e-5 at most) many times over
+        double S = 1.0;
+        for (const auto &st : filter->stages) {
+            double ss = 0.0;
+            for (float t : st.taps) ss += std::fabs((double)t);
+            S *= ss;
+        }
         if (S > 0.0) {
             // |v| < quiet_lsb  <=>  |v|/2048 < level (complexf.h:68-77 scaling)
             const double lvl = (double)cfg->threshold * 0.999 / (1.41421356237309515 * S) * 2048.0;
