@@ -170,14 +170,14 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
 
 template <bool EXACT>
-__global__ __launch_bounds__(kFirThreads) void fir1_bits_kernel(const FrontParams p) {
+__global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const FrontParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
     constexpr int R = kFirR;
     const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWaves + wave) * kWaveTile;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kWaveTile;
     const uint32_t Tp = p.stage[0].ntaps_pad;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
     float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots(Tp);
@@ -461,7 +461,7 @@ __device__ __noinline__ float2 fir2_exact_output(const uint32_t *lds0, const flo
     return make_float2(re2, im2);
 }
 
-constexpr int kFir2Waves = 2;           // ~10 KiB of LDS per wave: 2-wave workgroups pack 14 waves / CU
+constexpr int kFir2Waves = 1;           // single-wave workgroups: a loud wave must not pin the LDS / wave slots of finished quiet ones
 
 template <typename G, bool EXACT>
 __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontParams p) {
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64
 // ---------------------------------------------------------------------------
 
 static size_t fir1_lds_bytes(uint32_t Tp) {
-    return (size_t)kFirWaves * fir1_wave_slots(Tp) * sizeof(float2);
+    return (size_t)kFirWgWaves * fir1_wave_slots(Tp) * sizeof(float2);
 }
 
 static void gen_level_sizes(const FrontParams &p, uint32_t len[kMaxStages + 1]) {
@@ -889,19 +889,20 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
     if (use_fir1(p)) {
         const size_t lds = fir1_lds_bytes(p.stage[0].ntaps_pad);
         {
-            const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile;
+            // whole 4096-output blocks, so every bit word of the capture is written
+            const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * (kFirWaves / kFirWgWaves);
             dim3 grid((uint32_t)tiles, num_captures);
             hipError_t e;
             if (exact) {
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir1_bits_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(fir1_bits_kernel<true>, grid, dim3(kFirThreads), lds, stream, p);
+                hipLaunchKernelGGL(fir1_bits_kernel<true>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
             } else {
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir1_bits_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(fir1_bits_kernel<false>, grid, dim3(kFirThreads), lds, stream, p);
+                hipLaunchKernelGGL(fir1_bits_kernel<false>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
             }
             return hipGetLastError();
         }

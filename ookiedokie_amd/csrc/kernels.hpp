@@ -11,10 +11,11 @@ namespace ookd {
 
 constexpr int kMaxStages = 8;
 constexpr int kTapChunk = 32;           // taps are padded to a multiple of this
-constexpr int kFirThreads = 256;
+constexpr int kFirThreads = 256;        // lanes behind one 4096-output block of bit words
 constexpr int kFirR = 16;               // outputs per lane in the 1-stage kernel
 constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
-constexpr int kFirWaves = kFirThreads / 64;     // independent wavefronts per workgroup
+constexpr int kFirWaves = kFirThreads / 64;     // 1024-output wave tiles per 4096-output block
+constexpr int kFirWgWaves = 1;                  // wave tiles per workgroup of the 1-stage kernel
 constexpr int kWaveTile = 64 * kFirR;           // 1024 outputs per wavefront
 constexpr int kQuietCounters = 1024;
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
