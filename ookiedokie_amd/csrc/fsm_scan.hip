@@ -50,10 +50,13 @@ constexpr int kScanThreads = 1024;
 // reasons in the fallback word
 enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8 };
 
-// tables in LDS, structure of arrays
+// Tables in LDS, one 16-byte record per state / trigger: a simulation step is
+// a chain of dependent table reads (~100 cycles each), so what belongs
+// together is fetched with one ds_read_b128 and the triggers of a state in
+// batches of independent reads.
 struct LTab {
-    uint32_t tkmin[kMaxTriggers], tkmax[kMaxTriggers], tinfo[kMaxTriggers];
-    uint32_t skmin[kMaxStates], skmax[kMaxStates], skto[kMaxStates], srow[kMaxStates];
+    uint4 st[kMaxStates];       // kmin, kmax, kto, row = tbeg | tend << 8 | k-free << 16 | has msg_complete << 17
+    uint4 tr[kMaxTriggers];     // kmin, kmax, info = cond | action << 8 | next << 16, -
     uint32_t max_bits, S, NB1, D;       // NB1 = max_bits + 2 bit-count values; D = S*NB1 + 3
     uint32_t spb, decim;
 };
@@ -62,20 +65,16 @@ __device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kN
 
 __device__ void load_ltab(LTab &T, const FsmTablesDev *g, uint32_t spb, uint32_t decim) {
     for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxTriggers; i += blockDim.x) {
-        T.tkmin[i] = clamp32(g->trig_kmin[i]);
-        T.tkmax[i] = clamp32(g->trig_kmax[i]);
-        T.tinfo[i] = g->trig_info[i];
+        T.tr[i] = make_uint4(clamp32(g->trig_kmin[i]), clamp32(g->trig_kmax[i]), g->trig_info[i], 0u);
     }
     for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxStates; i += blockDim.x) {
-        T.skmin[i] = clamp32(g->state_kmin[i]);
-        T.skmax[i] = clamp32(g->state_kmax[i]);
-        T.skto[i] = clamp32(g->state_kto[i]);
         uint32_t msgc = 0;
         for (uint32_t t = g->state_tbeg[i]; t < g->state_tend[i] && t < (uint32_t)kMaxTriggers; ++t) {
             if ((g->trig_info[t] & 0xffu) == kCondMsgComplete) msgc = 1;
         }
-        T.srow[i] = (g->state_tbeg[i] & 0xffu) | ((g->state_tend[i] & 0xffu) << 8) |
-                    ((g->state_flags[i] & 1u) << 16) | (msgc << 17);
+        const uint32_t row = (g->state_tbeg[i] & 0xffu) | ((g->state_tend[i] & 0xffu) << 8) |
+                             ((g->state_flags[i] & 1u) << 16) | (msgc << 17);
+        T.st[i] = make_uint4(clamp32(g->state_kmin[i]), clamp32(g->state_kmax[i]), clamp32(g->state_kto[i]), row);
     }
     if (threadIdx.x == 0) {
         T.max_bits = g->max_bits;
@@ -116,43 +115,52 @@ __device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
 }
 
 __device__ __forceinline__ void canon(const LTab &T, PSim &f) {
-    if (T.srow[f.cur] & 0x10000u) f.k = 0;
+    if (T.st[f.cur].w & 0x10000u) f.k = 0;
 }
+
+constexpr int kTrigBatch = 4;           // trigger records fetched together
 
 // state_machine.c:421-519, one evaluation
 __device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
     const uint32_t s = f.cur;
-    const uint32_t row = T.srow[s];
-    const uint32_t te = (row >> 8) & 0xffu;
-    int fired = -1;
+    const uint4 srec = T.st[s];
+    const uint32_t te = (srec.w >> 8) & 0xffu;
+    const uint32_t max_bits = T.max_bits;
+    bool fired = false;
     uint32_t info = 0;
-    for (uint32_t t = row & 0xffu; t < te; ++t) {
-        if (f.k < T.tkmin[t] || f.k > T.tkmax[t]) continue;
-        info = T.tinfo[t];
-        const uint32_t c = info & 0xffu;
-        bool m;
-        if (c == kCondAlways) {
-            m = true;
-        } else if (c == kCondPulseStart) {
-            m = !f.prev && b;
-        } else if (c == kCondPulseEnd) {
-            m = f.prev && !b;
-        } else if (c == kCondTimeout) {
-            m = f.k >= T.skto[s];
-        } else {
-            m = f.nbits >= T.max_bits;
-            a.msgc_seen = true;
-            // table rows are simulated for a whole class of bit counts; that is
-            // only sound if this test is never reached after an append of the
-            // same span (and before a reset)
-            if (!a.reset_seen && a.napp > 0) a.sensitive = true;
-        }
-        if (m) {
-            fired = (int)t;
-            break;
+    for (uint32_t t0 = srec.w & 0xffu; t0 < te && !fired; t0 += kTrigBatch) {
+        uint4 rec[kTrigBatch];
+#pragma unroll
+        for (int j = 0; j < kTrigBatch; ++j) rec[j] = T.tr[(t0 + j) & (kMaxTriggers - 1)];
+#pragma unroll
+        for (int j = 0; j < kTrigBatch; ++j) {
+            if (fired || t0 + j >= te) continue;
+            if (f.k < rec[j].x || f.k > rec[j].y) continue;
+            const uint32_t c = rec[j].z & 0xffu;
+            bool m;
+            if (c == kCondAlways) {
+                m = true;
+            } else if (c == kCondPulseStart) {
+                m = !f.prev && b;
+            } else if (c == kCondPulseEnd) {
+                m = f.prev && !b;
+            } else if (c == kCondTimeout) {
+                m = f.k >= srec.z;
+            } else {
+                m = f.nbits >= max_bits;
+                a.msgc_seen = true;
+                // table rows are simulated for a whole class of bit counts; that is
+                // only sound if this test is never reached after an append of the
+                // same span (and before a reset)
+                if (!a.reset_seen && a.napp > 0) a.sensitive = true;
+            }
+            if (m) {
+                fired = true;
+                info = rec[j].z;
+            }
         }
     }
-    if (fired < 0) {
+    if (!fired) {
         f.k = sat_add(f.k, 1);
         return kResNone;
     }
@@ -160,7 +168,7 @@ __device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b
     const uint32_t fc = info & 0xffu, act = (info >> 8) & 0xffu, next = info >> 16;
     int result = kResNone;
     bool ok = true;
-    if (fc == kCondPulseStart || fc == kCondPulseEnd) ok = f.k >= T.skmin[s] && f.k <= T.skmax[s];
+    if (fc == kCondPulseStart || fc == kCondPulseEnd) ok = f.k >= srec.x && f.k <= srec.y;
     if (ok) {
         if (act == kActAppend0 || act == kActAppend1) {
             if (a.napp < kMaxLeafApps) {
@@ -213,28 +221,35 @@ __device__ __forceinline__ int p_step(const LTab &T, PSim &f, Acc &a, uint32_t b
 // evaluations until an always / timeout / msg_complete trigger fires while
 // the level stays constant (kNone = never)
 __device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &f, Acc &a) {
-    const uint32_t s = f.cur;
-    const uint32_t row = T.srow[s];
-    const uint32_t te = (row >> 8) & 0xffu;
-    const uint32_t kto = T.skto[s];
+    const uint4 srec = T.st[f.cur];
+    const uint32_t te = (srec.w >> 8) & 0xffu;
+    const uint32_t kto = srec.z;
+    const uint32_t max_bits = T.max_bits;
     uint32_t best = kNone;
-    for (uint32_t t = row & 0xffu; t < te; ++t) {
-        const uint32_t c = T.tinfo[t] & 0xffu;
-        uint32_t lo = T.tkmin[t];
-        if (c == kCondTimeout) {
-            if (kto == kNone) continue;
-            lo = lo > kto ? lo : kto;
-        } else if (c == kCondMsgComplete) {
-            a.msgc_seen = true;
-            if (!a.reset_seen && a.napp > 0) a.sensitive = true;
-            if (f.nbits < T.max_bits) continue;
-        } else if (c != kCondAlways) {
-            continue;
+    for (uint32_t t0 = srec.w & 0xffu; t0 < te; t0 += kTrigBatch) {
+        uint4 rec[kTrigBatch];
+#pragma unroll
+        for (int j = 0; j < kTrigBatch; ++j) rec[j] = T.tr[(t0 + j) & (kMaxTriggers - 1)];
+#pragma unroll
+        for (int j = 0; j < kTrigBatch; ++j) {
+            if (t0 + j >= te) continue;
+            const uint32_t c = rec[j].z & 0xffu;
+            uint32_t lo = rec[j].x;
+            if (c == kCondTimeout) {
+                if (kto == kNone) continue;
+                lo = lo > kto ? lo : kto;
+            } else if (c == kCondMsgComplete) {
+                a.msgc_seen = true;
+                if (!a.reset_seen && a.napp > 0) a.sensitive = true;
+                if (f.nbits < max_bits) continue;
+            } else if (c != kCondAlways) {
+                continue;
+            }
+            const uint32_t first = f.k > lo ? f.k : lo;
+            if (first > rec[j].y || first > kSat) continue;
+            const uint32_t w = first - f.k;
+            best = w < best ? w : best;
         }
-        const uint32_t first = f.k > lo ? f.k : lo;
-        if (first > T.tkmax[t] || first > kSat) continue;
-        const uint32_t w = first - f.k;
-        best = w < best ? w : best;
     }
     return best;
 }
@@ -317,9 +332,16 @@ __device__ __forceinline__ uint32_t code_poison(const LTab &T) { return T.S * T.
 // after the buffer of the edge that precedes the span (where a skip state
 // starts feeding samples again).  Returns alive (false = ends inside a
 // skip); f is the machine at the end.  Must not be called with the poison code.
-__device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f, Acc &a) {
-    const uint32_t nstates = T.S * T.NB1;
+// The machine and the record live in locals here (registers) and are copied
+// out once: worked on through the references they would sit in scratch memory.
+__device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f_out,
+                                      Acc &a_out) {
+    const uint32_t NB1 = T.NB1;
+    const uint32_t nstates = T.S * NB1;
+    PSim f;
+    Acc a;
     acc_init(a);
+    bool alive;
     if (code >= nstates) {
         f.cur = 0;
         f.nbits = 0;
@@ -327,21 +349,25 @@ __device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &
         f.prev = code - nstates;
         const uint64_t end_const = sp.pos0 + sp.n;
         const uint64_t last = end_const + (sp.has_edge ? 1 : 0);
-        if (resume >= last) return false;
-        if (resume >= end_const) return sim_span(T, f, a, resume, sp.L, 0, sp.has_edge);
-        return sim_span(T, f, a, resume, sp.L, end_const - resume, sp.has_edge);
+        if (resume >= last) alive = false;
+        else if (resume >= end_const) alive = sim_span(T, f, a, resume, sp.L, 0, sp.has_edge);
+        else alive = sim_span(T, f, a, resume, sp.L, end_const - resume, sp.has_edge);
+    } else {
+        f.cur = code / NB1;
+        f.nbits = code - f.cur * NB1;
+        f.k = 0;
+        f.prev = sp.L;
+        alive = sim_span(T, f, a, sp.pos0, sp.L, sp.n, sp.has_edge);
     }
-    f.cur = code / T.NB1;
-    f.nbits = code % T.NB1;
-    f.k = 0;
-    f.prev = sp.L;
-    return sim_span(T, f, a, sp.pos0, sp.L, sp.n, sp.has_edge);
+    f_out = f;
+    a_out = a;
+    return alive;
 }
 
 __device__ __forceinline__ uint32_t encode_post(const LTab &T, const PSim &f, const Acc &a, bool alive) {
     if (a.overflow) return code_poison(T);
     if (!alive) return code_skip(T, f.prev);
-    if (f.k != 0 && !(T.srow[f.cur] & 0x10000u)) return code_poison(T);   // counter not zeroed: not representable
+    if (f.k != 0 && !(T.st[f.cur].w & 0x10000u)) return code_poison(T);   // counter not zeroed: not representable
     return f.cur * T.NB1 + (f.nbits >= T.NB1 ? T.NB1 - 1 : f.nbits);
 }
 
@@ -400,16 +426,68 @@ __device__ __forceinline__ uint32_t parity_order(uint32_t p, uint32_t count) {
 // leaves of equal level (even leaves first, then odd), so they follow nearly
 // the same path.
 __shared__ uint32_t s_nuniq;
+__shared__ uint32_t s_sensitive;        // some row of the block needs per-count simulation
 
+// packed result of a class simulation
+constexpr uint32_t kPkAbsolute = 0x80000000u;   // [15:0] end code, [23:16] its state (S for skip / poison)
+constexpr uint32_t kPkSensitive = 0x40000000u;
+constexpr uint32_t kPkRelative = 0x20000000u;   // [7:0] end state, [23:8] appended bits
+
+__device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
+    return code | ((code / NB1) << 16) | kPkAbsolute;
+}
+
+// Abstract state as (state, bit count); state == S: nb 0 / 1 = skipping with
+// previous level 0 / 1, nb 2 = poison.
+struct AState {
+    uint32_t cur, nb;
+};
+
+__device__ __forceinline__ AState a_decode(uint32_t code, uint32_t NB1) {
+    AState st;
+    st.cur = code / NB1;        // NB1 >= 3, so the three special codes land in row S
+    st.nb = code - st.cur * NB1;
+    return st;
+}
+
+// One leaf applied to a state, straight from the packed class results of the
+// leaf (row = res + l * (2S+2)); false when the row needs the per-count tables.
+__device__ __forceinline__ bool a_apply(const uint32_t *row, AState &st, uint32_t S, uint32_t NB1, uint32_t max_bits) {
+    uint32_t pk;
+    if (st.cur >= S) {
+        if (st.nb >= 2) return true;                    // poison stays poison
+        pk = row[2 * S + st.nb];
+    } else {
+        pk = row[2 * st.cur + (st.nb >= max_bits ? 1u : 0u)];
+    }
+    if (pk & kPkAbsolute) {
+        const uint32_t code = pk & 0xffffu;
+        st.cur = (pk >> 16) & 0xffu;
+        st.nb = code - st.cur * NB1;
+        return true;
+    }
+    if (pk & kPkRelative) {
+        const uint32_t nbo = st.nb + ((pk >> 8) & 0xffffu);
+        st.cur = pk & 0xffu;
+        st.nb = nbo >= NB1 ? NB1 - 1 : nbo;
+        return true;
+    }
+    return false;
+}
+
+#define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
-                           uint64_t *resume, uint16_t *rep /* [count] */, uint16_t *uniq /* [count + 1] */) {
-    const uint32_t S = T.S, NB1 = T.NB1;
+                           uint64_t *resume, uint16_t *rep /* [count] */, uint16_t *uniq /* [count + 1] */,
+                           uint64_t *dbg = nullptr) {
+    STAMP(0);
+    const uint32_t S = T.S, NB1 = T.NB1, max_bits = T.max_bits;
     const uint32_t nsim = 2 * S + 2;
     // one 64-bit division per leaf instead of one per simulation
     for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) resume[l] = next_buffer_start(T, edges[first + l - 1]);
     // From a normal state the outcome of a span depends only on its level and
     // length, not on where it lies: simulate each distinct (level, length) of the
     // block once.  rep[l] = first leaf of the block with the same key.
+    STAMP(1);
     uint32_t *gap = res;                        // scratch: res is rewritten below
     for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
         const uint64_t n = edges[first + l] - edges[first + l - 1];
@@ -428,6 +506,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         rep[l] = (uint16_t)r;
     }
     __syncthreads();
+    STAMP(2);
     // list of representatives, even leaves first then odd ones (lanes of a wave
     // then share the level); position = rank in that order
     if (threadIdx.x == 0) uniq[0] = 0;
@@ -449,53 +528,70 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         s_nuniq = 0;
     }
     __syncthreads();
+    STAMP(3);
     const uint32_t nu = uniq[0];
-    const uint32_t upad = (nu + 63u) & ~63u, cpad = (count + 63u) & ~63u;
-    const uint32_t ntask = upad * S + cpad * 2;
-    for (uint32_t task = threadIdx.x; task < ntask; task += blockDim.x) {
+    // Wave-uniform tasks: a wavefront takes one start state (rows 0..S-1, then
+    // the two skip rows), its lanes the distinct spans (skip rows: the leaves,
+    // which are position dependent) -- lanes of a wave then run the same
+    // triggers and differ only in numbers.  With 16 waves per workgroup a
+    // device of up to 14 states is one round.
+    const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t row = wave; row < S + 2; row += nwaves) {
         PSim f;
         Acc a;
-        if (task >= upad * S) {
-            // skip states: position dependent, every leaf
-            const uint32_t t2 = task - upad * S;
-            const uint32_t k = t2 / cpad, lp = t2 - k * cpad;
-            const uint32_t l = parity_order(lp, count);
-            if (l >= count) continue;
-            const bool alive = run_leaf(T, code_skip(T, k), span_of(edges, first + l), resume[l], f, a);
-            res[l * nsim + 2 * S + k] = encode_post(T, f, a, alive) | 0x80000000u;     // absolute
+        if (row >= S) {
+            const uint32_t k = row - S;
+            for (uint32_t lp = lane; lp < count; lp += 64) {
+                const uint32_t l = parity_order(lp, count);
+                const bool alive = run_leaf(T, S * NB1 + k, span_of(edges, first + l), resume[l], f, a);
+                res[l * nsim + 2 * S + k] = pack_absolute(encode_post(T, f, a, alive), NB1);
+            }
             continue;
         }
-        const uint32_t k = task / upad, up = task - k * upad;
-        if (up >= nu) continue;
-        const uint32_t l = uniq[1 + up];
-        const Span sp = span_of(edges, first + l);
-        const uint64_t pe = resume[l];
-        for (uint32_t cls = 0; cls < 2; ++cls) {
-            const uint32_t nb0 = cls ? T.max_bits : 0u;
-            const bool alive = run_leaf(T, k * NB1 + nb0, sp, pe, f, a);
-            const uint32_t out = encode_post(T, f, a, alive);
-            uint32_t packed;
-            if (out >= S * NB1) {
-                packed = out | 0x80000000u;                     // skip / poison
-            } else if (a.sensitive) {
-                packed = 0x40000000u;                           // row needs one simulation per bit count
-            } else if (a.reset_seen) {
-                packed = out | 0x80000000u;                     // bit count restarted inside the span
-            } else {
-                const uint32_t ocur = out / NB1;
-                const uint32_t nbo = out - ocur * NB1;
-                const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
-                packed = ocur | (delta << 8) | 0x20000000u;     // relative: nb + delta (saturating)
-            }
-            res[l * nsim + 2 * k + cls] = packed;
-            if (cls == 0 && !a.msgc_seen && !a.overflow) {
-                // no dependence on the bit count at all: both classes share the run
-                res[l * nsim + 2 * k + 1] = packed;
-                break;
+        const uint32_t k = row;
+        for (uint32_t up = lane; up < nu; up += 64) {
+            const uint32_t l = uniq[1 + up];
+            const Span sp = span_of(edges, first + l);
+            const uint64_t pe = resume[l];
+            for (uint32_t cls = 0; cls < 2; ++cls) {
+                const uint32_t nb0 = cls ? max_bits : 0u;
+                if (dbg && threadIdx.x == 0 && cls == 0) dbg[5] = __builtin_amdgcn_s_memtime();
+                const bool alive = run_leaf(T, k * NB1 + nb0, sp, pe, f, a);
+                if (dbg && threadIdx.x == 0 && cls == 0) {
+                    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+                    dbg[6] = t1;
+                    PSim f2;
+                    Acc a2;
+                    run_leaf(T, k * NB1 + nb0, sp, pe, f2, a2);
+                    const uint64_t t2 = __builtin_amdgcn_s_memtime();
+                    dbg[7] = (t2 - t1) + ((uint64_t)a2.fires << 32);
+                }
+                const uint32_t out = encode_post(T, f, a, alive);
+                uint32_t packed;
+                if (out >= S * NB1) {
+                    packed = pack_absolute(out, NB1);               // skip / poison
+                } else if (a.sensitive) {
+                    packed = kPkSensitive;                          // row needs one simulation per bit count
+                    atomicOr(&s_sensitive, 1u);
+                } else if (a.reset_seen) {
+                    packed = pack_absolute(out, NB1);               // bit count restarted inside the span
+                } else {
+                    const uint32_t ocur = out / NB1;
+                    const uint32_t nbo = out - ocur * NB1;
+                    const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
+                    packed = ocur | (delta << 8) | kPkRelative;     // relative: nb + delta (saturating)
+                }
+                res[l * nsim + 2 * k + cls] = packed;
+                if (cls == 0 && !a.msgc_seen && !a.overflow) {
+                    // no dependence on the bit count at all: both classes share the run
+                    res[l * nsim + 2 * k + 1] = packed;
+                    break;
+                }
             }
         }
     }
     __syncthreads();
+    STAMP(4);
     // the other leaves take their representative's rows
     for (uint32_t e = threadIdx.x; e < count * 2 * S; e += blockDim.x) {
         const uint32_t l = e / (2 * S), c = e - l * (2 * S);
@@ -509,7 +605,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
 // item = (leaf, state row); a lane fills the row's NB1 entries.
 __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint16_t *tab,
                              const uint32_t *res, const uint64_t *resume) {
-    const uint32_t S = T.S, NB1 = T.NB1, D = T.D;
+    const uint32_t S = T.S, NB1 = T.NB1, D = T.D, max_bits = T.max_bits;
     const uint32_t nsim = 2 * S + 2;
     const uint32_t nrow = count * (S + 1);
     for (uint32_t item = threadIdx.x; item < nrow; item += blockDim.x) {
@@ -524,11 +620,11 @@ __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t firs
         }
         const uint32_t pk_lo = r[2 * cur], pk_hi = r[2 * cur + 1];
         for (uint32_t nb = 0; nb < NB1; ++nb) {
-            const uint32_t pk = nb >= T.max_bits ? pk_hi : pk_lo;
+            const uint32_t pk = nb >= max_bits ? pk_hi : pk_lo;
             uint32_t out;
-            if (pk & 0x80000000u) {
+            if (pk & kPkAbsolute) {
                 out = pk & 0xffffu;
-            } else if (pk & 0x20000000u) {
+            } else if (pk & kPkRelative) {
                 uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
                 if (nbo >= NB1) nbo = NB1 - 1;
                 out = (pk & 0xffu) * NB1 + nbo;
@@ -640,6 +736,23 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t count) {
     __syncthreads();
 }
 
+// The same without materialised leaf tables: every (chunk, state) walks the
+// packed class results directly.  Valid when no row of the block is
+// bit-count sensitive.
+__device__ void compose_chunks_packed(const LTab &T, const BlockLds &b, uint32_t count) {
+    const uint32_t S = T.S, NB1 = T.NB1, D = T.D, max_bits = T.max_bits;
+    const uint32_t nsim = 2 * S + 2;
+    const uint32_t nch = (count + kChunk - 1) / kChunk;
+    for (uint32_t item = threadIdx.x; item < nch * D; item += blockDim.x) {
+        const uint32_t c = item / D, d = item - c * D;
+        const uint32_t l1 = min((c + 1) * kChunk, count);
+        AState st = a_decode(d, NB1);
+        for (uint32_t l = c * kChunk; l < l1; ++l) a_apply(b.res + l * nsim, st, S, NB1, max_bits);
+        b.ctab[c * D + d] = (uint16_t)(st.cur * NB1 + st.nb);
+    }
+    __syncthreads();
+}
+
 // prefix of per-capture block counts: scan blocks (regular leaves) and finish
 // blocks (all leaves); one workgroup
 __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp) {
@@ -697,7 +810,10 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
-    if (threadIdx.x == 0) s_nuniq = 0;
+    if (threadIdx.x == 0) {
+        s_nuniq = 0;
+        s_sensitive = 0;
+    }
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
@@ -713,7 +829,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const uint64_t st0 = __builtin_amdgcn_s_memtime();
-        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq);
+        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq,
+                   (sp.f.debug && gb == 2) ? sp.f.debug + 40 : nullptr);
         const uint64_t st1 = __builtin_amdgcn_s_memtime();
         {
             // keep the packed results: the emit kernel rebuilds the tables from them
@@ -721,9 +838,13 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
             for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
         }
-        block_expand(T, edges, first, count, b.tab, b.res, s_resume);
+        const bool sensitive = s_sensitive != 0;
+        __syncthreads();
+        if (threadIdx.x == 0) s_sensitive = 0;
+        if (sensitive) block_expand(T, edges, first, count, b.tab, b.res, s_resume);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        compose_chunks(b, D, count);
+        if (sensitive) compose_chunks(b, D, count);
+        else compose_chunks_packed(T, b, count);
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;
@@ -857,6 +978,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
     __shared__ uint16_t cin[32];
+    if (threadIdx.x == 0) s_sensitive = 0;
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
@@ -877,14 +999,25 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             {
                 const uint32_t nsim = 2 * T.S + 2;
                 const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
-                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) b.res[i] = src[i];
+                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) {
+                    const uint32_t v = src[i];
+                    b.res[i] = v;
+                    if (!(v & (kPkAbsolute | kPkRelative))) atomicOr(&s_sensitive, 1u);
+                }
                 for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
                     s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
                 }
             }
             __syncthreads();
-            block_expand(T, edges, first, count, b.tab, b.res, s_resume);
-            compose_chunks(b, D, count);
+            const bool sensitive = s_sensitive != 0;
+            __syncthreads();
+            if (threadIdx.x == 0) s_sensitive = 0;
+            if (sensitive) {
+                block_expand(T, edges, first, count, b.tab, b.res, s_resume);
+                compose_chunks(b, D, count);
+            } else {
+                compose_chunks_packed(T, b, count);
+            }
             const uint32_t nch = (count + kChunk - 1) / kChunk;
             if (threadIdx.x == 0) {             // state entering each chunk
                 uint32_t s = sp.block_in[w];
@@ -897,17 +1030,29 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             if (threadIdx.x < nch) {            // state entering each leaf
                 const uint32_t c = threadIdx.x;
                 const uint32_t l1 = min((c + 1) * kChunk, count);
-                uint32_t s = cin[c];
-                for (uint32_t l = c * kChunk; l < l1; ++l) {
-                    pre[l] = (uint16_t)s;
-                    s = b.tab[l * D + s];
+                if (sensitive) {
+                    uint32_t s = cin[c];
+                    for (uint32_t l = c * kChunk; l < l1; ++l) {
+                        pre[l] = (uint16_t)s;
+                        s = b.tab[l * D + s];
+                    }
+                } else {
+                    const uint32_t nsim = 2 * T.S + 2;
+                    AState st = a_decode(cin[c], T.NB1);
+                    for (uint32_t l = c * kChunk; l < l1; ++l) {
+                        pre[l] = (uint16_t)(st.cur * T.NB1 + st.nb);
+                        a_apply(b.res + l * nsim, st, T.S, T.NB1, T.max_bits);
+                    }
                 }
             }
             __syncthreads();
-            for (uint32_t lp = threadIdx.x; lp < count; lp += blockDim.x) {
-                const uint32_t l = parity_order(lp, count);
+            // a wavefront takes the leaves entered in "its" states (state mod 16; skip
+            // and poison codes form row S), so its lanes run the same triggers
+            const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+            for (uint32_t l = threadIdx.x & 63u; l < count; l += 64) {
                 const uint64_t i = first + l;
                 const uint32_t in = pre[l];
+                if ((in / T.NB1) % nwaves != wave) continue;
                 PSim f;
                 Acc a;
                 bool alive = true;

@@ -590,8 +590,14 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     HIPCHK(hipEventRecord(ev[2], stream));
     if (getenv("OOKD_DEBUG_SCAN")) HIPCHK(hipStreamSynchronize(stream));
     if (getenv("OOKD_DEBUG_SCAN") && d_debug.p) {
-        uint64_t dbg[32];
+        uint64_t dbg[48];
         HIPCHK(hipMemcpy(dbg, d_debug.p, sizeof(dbg), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[scan] block_sims phases: resume %llu gap+rep %llu uniq %llu sims %llu\n",
+                (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
+                (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
+        fprintf(stderr, "[scan] run_leaf of wave 0: %llu ticks, repeated: %llu ticks, %llu fires\n",
+                (unsigned long long)(dbg[46] - dbg[45]), (unsigned long long)(dbg[47] & 0xffffffffu),
+                (unsigned long long)(dbg[47] >> 32));
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
@@ -890,7 +896,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rc |= rx->d_seg_msg_count.alloc(nseg);
         rc |= rx->d_seg_err_count.alloc(nseg);
         rc |= rx->d_seg_errs.alloc(nseg * rx->err_slots);
-        if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4);
+        if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4 + 64);
         // scan form: abstract states = states x bit counts + skip x2 + poison
         rx->scan_S = (uint32_t)device->state_duration_us.size();
         rx->scan_max_bits = device->num_bits;
