@@ -757,6 +757,36 @@ __global__ __launch_bounds__(1024) void fsm_gather_kernel(const FsmParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// publish: results straight into pinned host memory
+// ---------------------------------------------------------------------------
+// One small kernel instead of three device-to-host copy commands: the result
+// header (plus the edge total, which lives at the end of the block offsets)
+// and the first messages are written through the host-mapped pointers, then
+// the device header is zeroed for the next run.
+__global__ __launch_bounds__(256) void publish_kernel(PublishParams p) {
+    __shared__ uint64_t s_total;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_total = p.d_hdr[p.totals_word] | ((uint64_t)p.d_hdr[p.totals_word + 1] << 32);
+    __syncthreads();
+    if (p.d_msgs) {
+        const uint64_t n = (s_total < p.first_msgs ? s_total : p.first_msgs) * (sizeof(MsgDev) / 16);
+        for (uint64_t i = tid; i < n; i += blockDim.x) p.h_msgs[i] = p.d_msgs[i];
+    }
+    if (tid < p.hdr_words) {
+        uint32_t v = p.d_hdr[tid];
+        if (tid == p.edges_word && p.total_edges) v = *p.total_edges;
+        p.h_hdr[tid] = v;
+    }
+    __syncthreads();
+    if (tid < p.hdr_words) p.d_hdr[tid] = 0;
+}
+
+hipError_t launch_publish(const PublishParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 

@@ -162,6 +162,20 @@ hipError_t launch_fsm_round(const FsmParams &p, uint32_t parity, uint32_t mode, 
                             hipStream_t stream);
 hipError_t launch_fsm_gather(const FsmParams &p, hipStream_t stream);
 
+// ---- results -> pinned host memory ----------------------------------------------
+struct PublishParams {
+    uint32_t *d_hdr;                // device result header, as dwords; zeroed afterwards
+    uint32_t *h_hdr;                // host-mapped copy
+    uint32_t hdr_words;             // <= 256
+    uint32_t totals_word;           // dword index of the u64 message total
+    uint32_t edges_word;            // dword index that receives *total_edges
+    const uint32_t *total_edges;    // or null
+    const uint4 *d_msgs;            // or null (no state machine)
+    uint4 *h_msgs;
+    uint64_t first_msgs;            // messages published with the header
+};
+hipError_t launch_publish(const PublishParams &p, hipStream_t stream);
+
 // ---- state machine as a scan over edges (fsm_scan.hip) -----------------------------
 
 struct LeafEvDev {              // what happened in one edge-to-edge span

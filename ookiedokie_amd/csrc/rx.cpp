@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cinttypes>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -291,6 +292,9 @@ struct ookd_rx {
 
     ResultHeader *h_hdr = nullptr;  // pinned
     MsgDev *h_msgs = nullptr;       // pinned, msg_capacity
+    ResultHeader *h_hdr_dev = nullptr;      // the same two through the device's mapping
+    MsgDev *h_msgs_dev = nullptr;
+    bool hdr_dirty = true;          // device header needs zeroing before the next run
     uint64_t num_msgs = 0;
 
     // geometry of the last run
@@ -439,7 +443,8 @@ struct ookd_rx {
 
 int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                              uint32_t halo_len) {
-    HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    hdr_dirty = true;
     if (count_quiet) HIPCHK(hipMemsetAsync(d_quiet.p, 0, sizeof(uint32_t) * kQuietCounters, stream));
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
@@ -628,17 +633,26 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
 }
 
 int ookd_rx::fetch_results() {
-    HIPCHK(hipMemcpyAsync(h_hdr, d_hdr.p, sizeof(ResultHeader), hipMemcpyDeviceToHost, stream));
     const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
-    if (have_fsm && run_n_out > 0) {
-        HIPCHK(hipMemcpyAsync(h_msgs, d_msgs.p, first * sizeof(MsgDev), hipMemcpyDeviceToHost, stream));
+    {
+        static_assert(sizeof(ResultHeader) % 4 == 0 && sizeof(ResultHeader) / 4 <= 256, "header is published by one workgroup");
+        PublishParams pp{};
+        pp.d_hdr = reinterpret_cast<uint32_t *>(d_hdr.p);
+        pp.h_hdr = reinterpret_cast<uint32_t *>(h_hdr_dev);
+        pp.hdr_words = sizeof(ResultHeader) / 4;
+        pp.totals_word = offsetof(ResultHeader, totals) / 4;
+        pp.edges_word = offsetof(ResultHeader, total_edges) / 4;
+        pp.total_edges = run_n_out > 0 ? d_blk_offset.p + (size_t)run_caps * run_blocks : nullptr;
+        if (have_fsm && run_n_out > 0) {
+            pp.d_msgs = reinterpret_cast<const uint4 *>(d_msgs.p);
+            pp.h_msgs = reinterpret_cast<uint4 *>(h_msgs_dev);
+        }
+        pp.first_msgs = first;
+        HIPCHK(launch_publish(pp, stream));
     }
     uint32_t total_edges = 0;
-    if (run_n_out > 0) {
-        HIPCHK(hipMemcpyAsync(&h_hdr->total_edges, d_blk_offset.p + (size_t)run_caps * run_blocks,
-                              sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    }
     HIPCHK(hipStreamSynchronize(stream));
+    hdr_dirty = false;              // the publish kernel left the device header zeroed
     if (scan_pending) {
         scan_pending = false;
         if (h_hdr->scan_fallback == 0) {
@@ -650,8 +664,14 @@ int ookd_rx::fetch_results() {
             if (getenv("OOKD_DEBUG")) {
                 fprintf(stderr, "[ookd] fsm scan refused (reason %u), using rounds\n", h_hdr->scan_fallback);
             }
-            HIPCHK(hipMemsetAsync(d_hdr.p->totals, 0, sizeof(uint64_t) * 2, stream));
-            HIPCHK(hipMemsetAsync(&d_hdr.p->scan_fallback, 0, sizeof(uint32_t), stream));
+            // the publish kernel zeroed the device header: put the front end's
+            // counters back (minus the scan's verdict and totals) for the second pass
+            ResultHeader keep = *h_hdr;
+            keep.totals[0] = keep.totals[1] = 0;
+            keep.scan_fallback = 0;
+            HIPCHK(hipMemcpyAsync(d_hdr.p, &keep, sizeof(keep), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hdr_dirty = true;
             int rc = fsm_to_fixpoint(pending_first_valid ? &pending_first : nullptr, true, false);
             if (rc != OOKD_OK) return rc;
             stats.fsm_path = 3;
@@ -934,6 +954,11 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         return nullptr;
     }
     memset(rx->h_hdr, 0, sizeof(ResultHeader));
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rx->h_hdr_dev), rx->h_hdr, 0) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&rx->h_msgs_dev), rx->h_msgs, 0) != hipSuccess) {
+        set_error("pinned result buffers are not mapped into the device");
+        return nullptr;
+    }
     return rx.release();
 }
 
