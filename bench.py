@@ -102,12 +102,17 @@ def main():
     barrier()
     fir_ms, dev_ms = [], []
     t0 = time.perf_counter()
+    ptr = capture.data_ptr()
     for _ in range(args.steps):
-        res = rx.rx_device(capture.data_ptr(), n)
-        fir_ms.append(res.stats["fir_kernel_ms"])
-        dev_ms.append(res.stats["total_device_ms"])
+        # one step = one call through the C ABI: when it returns the decoded messages
+        # are in host memory; only the two timing floats are read back per step
+        rx.process_device(ptr, n)
+        st = rx.raw_stats()
+        fir_ms.append(st.fir_kernel_ms)
+        dev_ms.append(st.total_device_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    res = rx.result()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

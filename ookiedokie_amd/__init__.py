@@ -536,6 +536,22 @@ class Receiver:
                                             stride if stride is not None else samples_per_capture))
         return self._result()
 
+    def process_device(self, d_iq_ptr: int, samples_per_capture: int, num_captures: int = 1,
+                       stride: Optional[int] = None) -> None:
+        """ookd_rx_process_device and nothing else: when it returns the messages
+        are in host memory behind ookd_rx_messages(); `result()` / `raw_stats()`
+        turn them into Python objects when (and if) the caller wants them."""
+        _check(lib().ookd_rx_process_device(self._h, d_iq_ptr, num_captures, samples_per_capture,
+                                            stride if stride is not None else samples_per_capture))
+
+    def result(self) -> RxResult:
+        return self._result()
+
+    def raw_stats(self) -> RxStats:
+        s = RxStats()
+        _check(lib().ookd_rx_get_stats(self._h, C.byref(s)))
+        return s
+
     def rx(self, iq: np.ndarray) -> RxResult:
         """Host capture (staged over PCIe first)."""
         iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)

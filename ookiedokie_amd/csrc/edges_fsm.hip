@@ -75,7 +75,33 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
     const uint32_t base = blockIdx.x * kScanGroup + tid * 4;
     uint32_t v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (base + i < n) ? p.blk_count[base + i] : 0u;
+    for (int i = 0; i < 4; ++i) {
+        if (base + i >= n) {
+            v[i] = 0u;
+        } else if (!p.tile_info) {
+            v[i] = p.blk_count[base + i];
+        } else {
+            // block count from the wave tiles the front end already counted: changes
+            // inside each tile + one per tile whose first bit differs from the last bit
+            // of the tile before (nothing precedes a capture: level 0)
+            const uint32_t b = base + i;
+            const uint32_t cap = b / p.blocks_per_cap, blk = b - cap * p.blocks_per_cap;
+            const uint32_t tpb = p.tiles_per_block;
+            const uint32_t tile_bits = (uint32_t)(kBlockWords * 64) / tpb;
+            const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
+            const uint32_t t0 = blk * tpb;
+            uint32_t prev_last = t0 ? ti[t0 - 1] >> 31 : 0u;
+            uint32_t c = 0;
+            for (uint32_t t = 0; t < tpb; ++t) {
+                if ((uint64_t)(t0 + t) * tile_bits >= p.n_out) break;      // tile holds no sample
+                const uint32_t info = ti[t0 + t];
+                c += (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last);
+                prev_last = info >> 31;
+            }
+            v[i] = c;
+            p.blk_count[b] = c;         // edge_write skips empty blocks by it
+        }
+    }
     const uint32_t mine = v[0] + v[1] + v[2] + v[3];
     uint32_t inc = mine;
 #pragma unroll
@@ -795,7 +821,7 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
     if (total_blocks == 0) return hipSuccess;
     const uint32_t wgs = (total_blocks + 3) / 4;        // 4 waves per workgroup
     const uint32_t groups = (total_blocks + kScanGroup - 1) / kScanGroup;
-    hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
+    if (!p.tile_info) hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
     hipLaunchKernelGGL(edge_write_kernel, dim3(wgs), dim3(256), 0, stream, p);

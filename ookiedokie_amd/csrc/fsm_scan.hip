@@ -1420,14 +1420,11 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     const size_t lds_walk = (size_t)128 * sp.Dp * 2;
     if (lds_walk > 150u * 1024u) return hipErrorInvalidValue;
     hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_leaf_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_leaf_kernel), lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_emit_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_emit_kernel), lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_walk_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk);
+    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_walk_kernel), lds_walk);
     if (e != hipSuccess) return e;
     const uint32_t caps = a.f.num_captures;
     const uint32_t cap_grid = caps < 256 ? caps : 256;

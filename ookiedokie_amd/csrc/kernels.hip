@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <utility>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
             if (tid < kWaveTile / 64) words[(t0 >> 6) + tid] = 0;
+            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = 0;
             if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
             return;
         }
@@ -331,6 +333,22 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         for (int r = 0; r < R; ++r) {
             if (o0 + r < p.n_out) out[o0 + r] = make_float2(acc[r].x, acc[r].y);
         }
+    }
+
+    // level changes inside the tile (what edge_count would find in these 1024 bits,
+    // minus the comparison of the tile's first bit with the tile before)
+    {
+        const uint32_t keep = o0 >= p.n_out ? 0u : (o0 + R <= p.n_out ? (uint32_t)R : (uint32_t)(p.n_out - o0));
+        const uint32_t prev_top = __shfl_up(mask >> (R - 1), 1);       // bit 15 of the lane before
+        uint32_t ch = (mask ^ (mask << 1)) & 0xfffeu;
+        if (tid != 0) ch |= (mask ^ prev_top) & 1u;
+        ch &= keep >= 32 ? 0xffffffffu : ((1u << keep) - 1u);
+        uint32_t cnt = __popc(ch);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> (R - 1)) & 1u), 63);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31);
     }
 
     // four lanes x 16 bits -> one 64-bit word
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
             if (tid < G::F / 64) words[(J0 >> 6) + tid] = 0;
+            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = 0;
             if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
             return;
         }
@@ -575,6 +594,20 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
         }
         nib |= ((valid && bit) ? 1u : 0u) << r;
         if (fout && valid) fout[o0 + r] = make_float2(acc[r].x, acc[r].y);
+    }
+    {
+        // level changes inside the tile, as in the 1-stage kernel
+        const uint32_t keep = o0 >= p.n_out ? 0u : (o0 + G::R2 <= p.n_out ? (uint32_t)G::R2 : (uint32_t)(p.n_out - o0));
+        const uint32_t prev_top = __shfl_up(nib >> (G::R2 - 1), 1);
+        uint32_t ch = (nib ^ (nib << 1)) & ((1u << G::R2) - 2u);
+        if (tid != 0) ch |= (nib ^ prev_top) & 1u;
+        ch &= (1u << keep) - 1u;
+        uint32_t cnt = __popc(ch);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nib & 1u));
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((nib >> (G::R2 - 1)) & 1u), 63);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = cnt | (first << 30) | (last << 31);
     }
     uint32_t half = nib << (4u * (tid & 7u));
     half |= __shfl_xor(half, 1);
@@ -844,17 +877,37 @@ hipError_t launch_front_generic(const FrontParams &p, uint32_t num_captures, hip
     dim3 grid((uint32_t)tiles, num_captures);
     hipError_t e;
     if (p.iq_f32) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir_generic_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir_generic_kernel<true>), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fir_generic_kernel<true>, grid, dim3(256), lds, stream, p, even + 1);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir_generic_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir_generic_kernel<false>), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fir_generic_kernel<false>, grid, dim3(256), lds, stream, p, even + 1);
     }
     return hipGetLastError();
+}
+
+hipError_t ensure_dynamic_lds(const void *func, size_t bytes) {
+    struct Granted {
+        const void *func;
+        int dev;
+        size_t bytes;
+    };
+    static thread_local std::vector<Granted> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (Granted &g : granted) {
+        if (g.func == func && g.dev == dev) {
+            if (g.bytes >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) g.bytes = bytes;
+            return e;
+        }
+    }
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted.push_back({func, dev, bytes});
+    return e;
 }
 
 static bool use_fir1(const FrontParams &p) {
@@ -877,6 +930,12 @@ uint64_t front_wave_tiles(const FrontParams &p) {
     return 0;
 }
 
+uint32_t front_tile_bits(const FrontParams &p) {
+    if (use_fir1(p)) return kWaveTile;
+    if (use_fir2(p)) return Fir2Dec4::F;
+    return 0;
+}
+
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream) {
     if (p.n_out == 0) return hipSuccess;
     if (p.num_stages == 0) {
@@ -894,13 +953,11 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
             dim3 grid((uint32_t)tiles, num_captures);
             hipError_t e;
             if (exact) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir1_bits_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir1_bits_kernel<true>), lds);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(fir1_bits_kernel<true>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
             } else {
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fir1_bits_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir1_bits_kernel<false>), lds);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(fir1_bits_kernel<false>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
             }

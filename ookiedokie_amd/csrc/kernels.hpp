@@ -52,13 +52,23 @@ struct FrontParams {
     int quiet_lsb;              // all |I|,|Q| of a window below this (raw LSB) => outputs provably < threshold
     unsigned long long *recompute_count;
     uint32_t *quiet_count;      // kQuietCounters spread counters of waves that skipped the filter, or null
+    uint32_t *tile_info;        // tuned kernels: per wave tile, level changes inside the tile
+                                // (its first bit vs. the tile before NOT included)
+                                // | first bit << 30 | last bit << 31; [captures][tiles_per_cap]
+    uint32_t tiles_per_cap;
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a kernel needs
+// more than it was last granted (the call costs microseconds per launch).
+hipError_t ensure_dynamic_lds(const void *func, size_t bytes);
 
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
                         hipStream_t stream);
 // 1024-ish output windows ("wave tiles") the tuned kernels split a capture into
 // (0 when the generic kernel serves this shape).
 uint64_t front_wave_tiles(const FrontParams &p);
+// bits per wave tile of the tuned kernel that serves this shape (0 = generic)
+uint32_t front_tile_bits(const FrontParams &p);
 // Generic multi-stage kernel regardless of shape (cross-check / streaming FIR).
 hipError_t launch_front_generic(const FrontParams &p, uint32_t num_captures,
                                 hipStream_t stream);
@@ -80,6 +90,8 @@ struct EdgeParams {
     uint64_t *edges;            // capture-local decimated indices
     uint64_t edge_capacity;
     uint32_t *overflow;         // set to 1 when total edges > capacity
+    const uint32_t *tile_info;  // per wave tile counts from the tuned front-end kernels, or null
+    uint32_t tiles_per_block;   // wave tiles per 4096-bit block (4 or 16)
 };
 
 hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);

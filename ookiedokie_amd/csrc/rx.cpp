@@ -240,6 +240,7 @@ struct ookd_rx {
     bool exact = false;
     bool count_quiet = false;
     DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics)
+    DevBuf<uint32_t> d_tile_info;   // per wave tile edge counts written by the tuned front-end kernels
 
     // device (state machine)
     bool have_fsm = false;
@@ -382,6 +383,11 @@ struct ookd_rx {
         p.recompute_count = &d_hdr.p->recompute;
         p.quiet_lsb = quiet_lsb;
         p.quiet_count = count_quiet ? d_quiet.p : nullptr;
+        p.tile_info = d_tile_info.p;
+        {
+            const uint32_t tile_bits = front_tile_bits(p);
+            p.tiles_per_cap = tile_bits ? (uint32_t)(run_words * 64 / tile_bits) : 0;
+        }
         return p;
     }
 
@@ -398,6 +404,11 @@ struct ookd_rx {
         e.edges = d_edges.p;
         e.edge_capacity = edge_capacity;
         e.overflow = &d_hdr.p->edge_overflow;
+        const uint32_t tile_bits = front_tile_bits(front_params(nullptr, 0));
+        if (tile_bits && d_tile_info.p) {
+            e.tile_info = d_tile_info.p;
+            e.tiles_per_block = (uint32_t)(kBlockWords * 64) / tile_bits;
+        }
         return e;
     }
 
@@ -901,6 +912,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     if (cfg->flags & OOKD_RX_KEEP_FIR) rc |= rx->d_fir.alloc(2 * caps * rx->max_n_out + 2);
     rc |= rx->d_halo.alloc(2 * (rx->halo_needed + 4));
     rc |= rx->d_blk_count.alloc(caps * blocks + 1);
+    rc |= rx->d_tile_info.alloc(caps * blocks * 16 + 16);       // smallest wave tile: 256 bits
     rc |= rx->d_blk_offset.alloc(caps * blocks + 1);
     rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
