@@ -155,32 +155,50 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
 }
 
 // level 3 fused with the compaction: add the group base, keep the global
-// prefix for later readers, write the positions.
+// prefix for later readers, write the positions.  A wavefront owns
+// kWriteSpan consecutive blocks: their counts / offsets are fetched by its
+// first lanes in one go, then only the blocks that hold edges (a minority:
+// OOK is mostly constant level) get the 64-word treatment.
+constexpr uint32_t kWriteSpan = 16;
+
 __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = lane_id();
     const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
-    if (wave >= total_blocks) return;
-    const uint32_t off = p.blk_offset[wave] + p.group_total[wave / kScanGroup];
-    if (lane_id() == 0) p.blk_offset[wave] = off;
-    if (p.blk_count[wave] == 0) return;
-    const uint32_t cap = wave / p.blocks_per_cap;
-    const uint32_t blk = wave % p.blocks_per_cap;
-    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-    const uint64_t w = (uint64_t)blk * kBlockWords + lane_id();
-    uint64_t e = change_word(words, w, p.n_out);
-    const uint32_t c = (uint32_t)__popcll(e);
-    uint32_t inc = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(inc, d);
-        if ((int)lane_id() >= d) inc += v;
+    const uint32_t b0 = wave * kWriteSpan;
+    if (b0 >= total_blocks) return;
+    uint32_t off = 0, cnt = 0;
+    if (lane < kWriteSpan && b0 + lane < total_blocks) {
+        const uint32_t b = b0 + lane;
+        off = p.blk_offset[b] + p.group_total[b / kScanGroup];
+        p.blk_offset[b] = off;
+        cnt = p.blk_count[b];
     }
-    uint64_t at = (uint64_t)off + (inc - c);
-    while (e) {
-        const int b = __ffsll((long long)e) - 1;
-        if (at < p.edge_capacity) p.edges[at] = w * 64 + (uint64_t)b;
-        ++at;
-        e &= e - 1;
+    uint64_t todo = __ballot(cnt != 0);
+    while (todo) {
+        const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+        todo &= todo - 1;
+        const uint32_t b = b0 + j;
+        const uint32_t boff = rl(off, j);
+        const uint32_t cap = b / p.blocks_per_cap;
+        const uint32_t blk = b % p.blocks_per_cap;
+        const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+        const uint64_t w = (uint64_t)blk * kBlockWords + lane;
+        uint64_t e = change_word(words, w, p.n_out);
+        const uint32_t c = (uint32_t)__popcll(e);
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += v;
+        }
+        uint64_t at = (uint64_t)boff + (inc - c);
+        while (e) {
+            const int bit = __ffsll((long long)e) - 1;
+            if (at < p.edge_capacity) p.edges[at] = w * 64 + (uint64_t)bit;
+            ++at;
+            e &= e - 1;
+        }
     }
 }
 
@@ -824,7 +842,8 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
     if (!p.tile_info) hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
-    hipLaunchKernelGGL(edge_write_kernel, dim3(wgs), dim3(256), 0, stream, p);
+    const uint32_t write_waves = (total_blocks + kWriteSpan - 1) / kWriteSpan;
+    hipLaunchKernelGGL(edge_write_kernel, dim3((write_waves + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -555,17 +555,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
             const uint64_t pe = resume[l];
             for (uint32_t cls = 0; cls < 2; ++cls) {
                 const uint32_t nb0 = cls ? max_bits : 0u;
-                if (dbg && threadIdx.x == 0 && cls == 0) dbg[5] = __builtin_amdgcn_s_memtime();
                 const bool alive = run_leaf(T, k * NB1 + nb0, sp, pe, f, a);
-                if (dbg && threadIdx.x == 0 && cls == 0) {
-                    const uint64_t t1 = __builtin_amdgcn_s_memtime();
-                    dbg[6] = t1;
-                    PSim f2;
-                    Acc a2;
-                    run_leaf(T, k * NB1 + nb0, sp, pe, f2, a2);
-                    const uint64_t t2 = __builtin_amdgcn_s_memtime();
-                    dbg[7] = (t2 - t1) + ((uint64_t)a2.fires << 32);
-                }
                 const uint32_t out = encode_post(T, f, a, alive);
                 uint32_t packed;
                 if (out >= S * NB1) {
@@ -1339,16 +1329,24 @@ __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
             const uint8_t *vals = sp.app_vals + pool_start(e0, mm.capture);
             const uint32_t ep = (uint32_t)mm.payload[0], have = (uint32_t)(mm.payload[0] >> 32);
             const uint32_t take = min(have, min(max_bits + 1, 256u));
-            uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-            for (uint32_t t = 0; t < take; ++t) {
-                const uint64_t bit = vals[ep + t] ? (1ull << (t & 63)) : 0ull;
-                const uint32_t q = t >> 6;
-                w0 |= q == 0 ? bit : 0ull;
-                w1 |= q == 1 ? bit : 0ull;
-                w2 |= q == 2 ? bit : 0ull;
-                w3 |= q == 3 ? bit : 0ull;
+            // append values are bytes 0 / 1: eight at a time, squeezed to a byte of bits
+            uint64_t wv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                uint64_t w = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < 8; ++g) {
+                    const uint32_t t = 64 * q + 8 * g;
+                    if (t < take) {
+                        uint64_t x = 0;
+                        __builtin_memcpy(&x, vals + ep + t, 8);        // the pool is padded past its end
+                        const uint32_t left = take - t;
+                        if (left < 8) x &= (1ull << (8 * left)) - 1ull;
+                        w |= ((x * 0x0102040810204080ull) >> 56) << (8 * g);
+                    }
+                }
+                wv[q] = w;
             }
-            const uint64_t wv[4] = {w0, w1, w2, w3};
             for (uint32_t q = 0; q < 4; ++q) {
                 uint64_t v = wv[q];
                 if (8 * q >= nbytes) v = 0;

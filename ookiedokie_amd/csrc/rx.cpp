@@ -590,7 +590,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.total_blocks_cap = scan_blocks_cap;
     a.events = d_events.p;
     a.app_vals = d_app_vals.p;
-    a.app_capacity = d_app_vals.n;
+    a.app_capacity = d_app_vals.n - 64;     // fin_msg reads whole 8-byte groups
     a.errs = d_scan_errs.p;
     a.err_capacity = d_scan_errs.n;
     a.first = first;
@@ -611,9 +611,6 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
         fprintf(stderr, "[scan] block_sims phases: resume %llu gap+rep %llu uniq %llu sims %llu\n",
                 (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
                 (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
-        fprintf(stderr, "[scan] run_leaf of wave 0: %llu ticks, repeated: %llu ticks, %llu fires\n",
-                (unsigned long long)(dbg[46] - dbg[45]), (unsigned long long)(dbg[47] & 0xffffffffu),
-                (unsigned long long)(dbg[47] >> 32));
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
