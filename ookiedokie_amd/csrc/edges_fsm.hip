@@ -156,20 +156,22 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
 
 // level 3 fused with the compaction: add the group base, keep the global
 // prefix for later readers, write the positions.  A wavefront owns
-// kWriteSpan consecutive blocks: their counts / offsets are fetched by its
-// first lanes in one go, then only the blocks that hold edges (a minority:
-// OOK is mostly constant level) get the 64-word treatment.
+// kWriteSpan blocks, interleaved with the other wavefronts' (blocks with
+// edges come in runs -- a message -- and would otherwise pile up on a few
+// waves): their counts / offsets are fetched by its first lanes in one go,
+// then only the blocks that hold edges (a minority: OOK is mostly constant
+// level) get the 64-word treatment.
 constexpr uint32_t kWriteSpan = 16;
 
 __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = lane_id();
     const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
-    const uint32_t b0 = wave * kWriteSpan;
-    if (b0 >= total_blocks) return;
+    const uint32_t nwaves = (total_blocks + kWriteSpan - 1) / kWriteSpan;
+    if (wave >= nwaves) return;
     uint32_t off = 0, cnt = 0;
-    if (lane < kWriteSpan && b0 + lane < total_blocks) {
-        const uint32_t b = b0 + lane;
+    if (lane < kWriteSpan && wave + lane * nwaves < total_blocks) {
+        const uint32_t b = wave + lane * nwaves;
         off = p.blk_offset[b] + p.group_total[b / kScanGroup];
         p.blk_offset[b] = off;
         cnt = p.blk_count[b];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
     while (todo) {
         const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
         todo &= todo - 1;
-        const uint32_t b = b0 + j;
+        const uint32_t b = wave + j * nwaves;
         const uint32_t boff = rl(off, j);
         const uint32_t cap = b / p.blocks_per_cap;
         const uint32_t blk = b % p.blocks_per_cap;

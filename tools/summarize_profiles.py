@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<round>/ (tools/collect_profiles.sh) into the tracked
+files under profiles/:
+
+    python tools/summarize_profiles.py r01
+
+  <round>_kernel_stats.csv       rocprofv3 --kernel-trace --stats summary
+  traffic.json                   HBM bytes per launch of the front-end kernel
+                                 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes)
+  <round>_bench_line*.json       the bench lines of the same build
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "fir1_bits_kernel"
+ALGO_BYTES = 4.125 * (1 << 28)
+
+
+def counter_avg(dirname, counter):
+    vals = []
+    for f in glob.glob(os.path.join(dirname, "*", "*counter_collection.csv")):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) > (1 << 22):
+                    vals.append(float(r["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
+    dst = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, rnd + "_kernel_stats.csv"))
+    fetch, nf = counter_avg(os.path.join(src, "fetch"), "FETCH_SIZE")
+    write, nw = counter_avg(os.path.join(src, "write"), "WRITE_SIZE")
+    if fetch is not None and write is not None:
+        hbm = (2.0 * fetch + write) * 1024.0
+        with open(os.path.join(dst, "traffic.json"), "w") as f:
+            json.dump({
+                "kernel": "ookd::" + KERNEL + "<false>",
+                "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python "
+                           "bench.py --steps 5 --warmup 1 --no-cpu-baseline (two separate passes, "
+                           "tools/collect_profiles.sh)",
+                "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write, "launches": [nf, nw],
+                "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane streaming reads "
+                              "-> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
+                "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ALGO_BYTES,
+            }, f, indent=1)
+        print("traffic: %.4f GB per launch (algorithmic %.4f GB)" % (hbm / 1e9, ALGO_BYTES / 1e9))
+    for name in ("bench_line", "bench_line_no_quiet_skip", "bench_line_dec4"):
+        p = os.path.join(src, name + ".json")
+        if os.path.exists(p):
+            with open(p) as f:
+                lines = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+            if lines:
+                with open(os.path.join(dst, "%s_%s.json" % (rnd, name)), "w") as f:
+                    f.write(lines[-1] + "\n")
+                j = json.loads(lines[-1])
+                print(name, j["value"], j["roofline"]["frac"], j["roofline"]["avg_kernel_ms"])
+
+
+if __name__ == "__main__":
+    main()
