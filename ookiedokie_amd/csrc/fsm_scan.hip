@@ -332,12 +332,69 @@ __device__ __forceinline__ uint32_t code_poison(const LTab &T) { return T.S * T.
 // after the buffer of the edge that precedes the span (where a skip state
 // starts feeding samples again).  Returns alive (false = ends inside a
 // skip); f is the machine at the end.  Must not be called with the poison code.
-// The machine and the record live in locals here (registers) and are copied
-// out once: worked on through the references they would sit in scratch memory.
-__device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f_out,
-                                      Acc &a_out) {
+// What a simulation hands back, squeezed into 12 dwords so that the
+// out-of-line simulator returns it in registers.  (Passing the span and the
+// records by reference put them in scratch memory: two round trips of
+// several hundred cycles per call.)
+struct SimRes {
+    uint32_t w[12];
+};
+
+__device__ __forceinline__ SimRes sim_pack(const PSim &f, const Acc &a, bool alive) {
+    SimRes r;
+    r.w[0] = (f.cur & 0xffu) | ((f.prev & 1u) << 8) | ((alive ? 1u : 0u) << 9) | ((a.reset_seen ? 1u : 0u) << 10) |
+             ((a.sensitive ? 1u : 0u) << 11) | ((a.overflow ? 1u : 0u) << 12) | ((a.msgc_seen ? 1u : 0u) << 13);
+    r.w[1] = f.k;
+    r.w[2] = f.nbits;
+    r.w[3] = (a.napp > 255u ? 255u : a.napp) | ((a.nout > 255u ? 255u : a.nout) << 8) |
+             ((a.nerr > 255u ? 255u : a.nerr) << 16) | ((a.apps_at_reset & 0xffu) << 24);
+    r.w[4] = a.appvals;
+    r.w[5] = (a.out_ab0 & 0xffu) | ((a.out_ab1 & 0xffu) << 8) | ((a.out_rb0 & 0xffu) << 16) | ((a.out_rb1 & 0xffu) << 24);
+    r.w[6] = (uint32_t)a.out_pos0;
+    r.w[7] = (uint32_t)(a.out_pos0 >> 32);
+    r.w[8] = (uint32_t)a.out_pos1;
+    r.w[9] = (uint32_t)(a.out_pos1 >> 32);
+    r.w[10] = (uint32_t)a.err_pos;
+    r.w[11] = (uint32_t)(a.err_pos >> 32);
+    return r;
+}
+
+// -> alive
+__device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Acc &a) {
+    f.cur = r.w[0] & 0xffu;
+    f.prev = (r.w[0] >> 8) & 1u;
+    f.k = r.w[1];
+    f.nbits = r.w[2];
+    a.reset_seen = (r.w[0] >> 10) & 1u;
+    a.sensitive = (r.w[0] >> 11) & 1u;
+    a.overflow = (r.w[0] >> 12) & 1u;
+    a.msgc_seen = (r.w[0] >> 13) & 1u;
+    a.napp = r.w[3] & 0xffu;
+    a.nout = (r.w[3] >> 8) & 0xffu;
+    a.nerr = (r.w[3] >> 16) & 0xffu;
+    a.apps_at_reset = r.w[3] >> 24;
+    a.appvals = r.w[4];
+    a.out_ab0 = r.w[5] & 0xffu;
+    a.out_ab1 = (r.w[5] >> 8) & 0xffu;
+    a.out_rb0 = (r.w[5] >> 16) & 0xffu;
+    a.out_rb1 = r.w[5] >> 24;
+    a.out_pos0 = r.w[6] | ((uint64_t)r.w[7] << 32);
+    a.out_pos1 = r.w[8] | ((uint64_t)r.w[9] << 32);
+    a.err_pos = r.w[10] | ((uint64_t)r.w[11] << 32);
+    a.fires = 0;
+    return (r.w[0] >> 9) & 1u;
+}
+
+// Concrete run of a span from abstract state `code`; `resume` = first sample
+// after the buffer of the edge that precedes the span (where a skip state
+// starts feeding samples again).  alive = false: ends inside a skip.  Must not
+// be called with the poison code.  lvl_edge = level | has_edge << 1.
+__device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t code, uint64_t pos0, uint64_t n, uint32_t lvl_edge,
+                                            uint64_t resume) {
     const uint32_t NB1 = T.NB1;
     const uint32_t nstates = T.S * NB1;
+    const uint32_t L = lvl_edge & 1u;
+    const bool has_edge = (lvl_edge & 2u) != 0;
     PSim f;
     Acc a;
     acc_init(a);
@@ -347,21 +404,27 @@ __device__ __noinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &
         f.nbits = 0;
         f.k = 0;
         f.prev = code - nstates;
-        const uint64_t end_const = sp.pos0 + sp.n;
-        const uint64_t last = end_const + (sp.has_edge ? 1 : 0);
+        const uint64_t end_const = pos0 + n;
+        const uint64_t last = end_const + (has_edge ? 1 : 0);
         if (resume >= last) alive = false;
-        else if (resume >= end_const) alive = sim_span(T, f, a, resume, sp.L, 0, sp.has_edge);
-        else alive = sim_span(T, f, a, resume, sp.L, end_const - resume, sp.has_edge);
+        else if (resume >= end_const) alive = sim_span(T, f, a, resume, L, 0, has_edge);
+        else alive = sim_span(T, f, a, resume, L, end_const - resume, has_edge);
     } else {
         f.cur = code / NB1;
         f.nbits = code - f.cur * NB1;
         f.k = 0;
-        f.prev = sp.L;
-        alive = sim_span(T, f, a, sp.pos0, sp.L, sp.n, sp.has_edge);
+        f.prev = L;
+        alive = sim_span(T, f, a, pos0, L, n, has_edge);
     }
-    f_out = f;
-    a_out = a;
-    return alive;
+    // the 8-bit event counters of the record saturate; more than the record can
+    // hold is an overflow anyway (kMaxLeafApps, two outputs, one error)
+    return sim_pack(f, a, alive);
+}
+
+__device__ __forceinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f,
+                                         Acc &a) {
+    const SimRes r = run_leaf_raw(T, code, sp.pos0, sp.n, sp.L | (sp.has_edge ? 2u : 0u), resume);
+    return sim_unpack(r, f, a);
 }
 
 __device__ __forceinline__ uint32_t encode_post(const LTab &T, const PSim &f, const Acc &a, bool alive) {
@@ -395,6 +458,7 @@ struct ScanParams {
     unsigned long long *cap_base;   // [captures][2] message / error slot bases
     uint32_t fin_blocks_cap;
     uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
+    uint16_t *leaf_rep;         // [edges + captures] block-local index of the leaf whose normal rows this one shares
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -426,53 +490,15 @@ __device__ __forceinline__ uint32_t parity_order(uint32_t p, uint32_t count) {
 // leaves of equal level (even leaves first, then odd), so they follow nearly
 // the same path.
 __shared__ uint32_t s_nuniq;
-__shared__ uint32_t s_sensitive;        // some row of the block needs per-count simulation
 
 // packed result of a class simulation
 constexpr uint32_t kPkAbsolute = 0x80000000u;   // [15:0] end code, [23:16] its state (S for skip / poison)
 constexpr uint32_t kPkSensitive = 0x40000000u;
 constexpr uint32_t kPkRelative = 0x20000000u;   // [7:0] end state, [23:8] appended bits
+constexpr uint32_t kPkShared = 0x10000000u;     // transient: class "all bits" takes this result too
 
 __device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
     return code | ((code / NB1) << 16) | kPkAbsolute;
-}
-
-// Abstract state as (state, bit count); state == S: nb 0 / 1 = skipping with
-// previous level 0 / 1, nb 2 = poison.
-struct AState {
-    uint32_t cur, nb;
-};
-
-__device__ __forceinline__ AState a_decode(uint32_t code, uint32_t NB1) {
-    AState st;
-    st.cur = code / NB1;        // NB1 >= 3, so the three special codes land in row S
-    st.nb = code - st.cur * NB1;
-    return st;
-}
-
-// One leaf applied to a state, straight from the packed class results of the
-// leaf (row = res + l * (2S+2)); false when the row needs the per-count tables.
-__device__ __forceinline__ bool a_apply(const uint32_t *row, AState &st, uint32_t S, uint32_t NB1, uint32_t max_bits) {
-    uint32_t pk;
-    if (st.cur >= S) {
-        if (st.nb >= 2) return true;                    // poison stays poison
-        pk = row[2 * S + st.nb];
-    } else {
-        pk = row[2 * st.cur + (st.nb >= max_bits ? 1u : 0u)];
-    }
-    if (pk & kPkAbsolute) {
-        const uint32_t code = pk & 0xffffu;
-        st.cur = (pk >> 16) & 0xffu;
-        st.nb = code - st.cur * NB1;
-        return true;
-    }
-    if (pk & kPkRelative) {
-        const uint32_t nbo = st.nb + ((pk >> 8) & 0xffffu);
-        st.cur = pk & 0xffu;
-        st.nb = nbo >= NB1 ? NB1 - 1 : nbo;
-        return true;
-    }
-    return false;
 }
 
 #define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -530,54 +556,55 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
     __syncthreads();
     STAMP(3);
     const uint32_t nu = uniq[0];
-    // Wave-uniform tasks: a wavefront takes one start state (rows 0..S-1, then
-    // the two skip rows), its lanes the distinct spans (skip rows: the leaves,
-    // which are position dependent) -- lanes of a wave then run the same
-    // triggers and differ only in numbers.  With 16 waves per workgroup a
-    // device of up to 14 states is one round.
-    const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t row = wave; row < S + 2; row += nwaves) {
+    // Dense tasks, one per lane: (start state, distinct span, class) for the normal
+    // rows, then the two skip states of every leaf (position dependent).  The
+    // machine is busy with the instruction streams of these waves and nothing
+    // else, so lanes must not idle: neighbouring lanes share the start state
+    // (same triggers, mostly the same path), and both classes run side by side.
+    const uint32_t nnorm = 2 * nu * S;
+    const uint32_t ntask = nnorm + 2 * count;
+    for (uint32_t task = threadIdx.x; task < ntask; task += blockDim.x) {
         PSim f;
         Acc a;
-        if (row >= S) {
-            const uint32_t k = row - S;
-            for (uint32_t lp = lane; lp < count; lp += 64) {
-                const uint32_t l = parity_order(lp, count);
-                const bool alive = run_leaf(T, S * NB1 + k, span_of(edges, first + l), resume[l], f, a);
-                res[l * nsim + 2 * S + k] = pack_absolute(encode_post(T, f, a, alive), NB1);
-            }
+        if (task >= nnorm) {
+            const uint32_t t2 = task - nnorm;
+            const uint32_t k = t2 / count, lp = t2 - k * count;
+            const uint32_t l = parity_order(lp, count);
+            const bool alive = run_leaf(T, S * NB1 + k, span_of(edges, first + l), resume[l], f, a);
+            res[l * nsim + 2 * S + k] = pack_absolute(encode_post(T, f, a, alive), NB1);
             continue;
         }
-        const uint32_t k = row;
-        for (uint32_t up = lane; up < nu; up += 64) {
-            const uint32_t l = uniq[1 + up];
-            const Span sp = span_of(edges, first + l);
-            const uint64_t pe = resume[l];
-            for (uint32_t cls = 0; cls < 2; ++cls) {
-                const uint32_t nb0 = cls ? max_bits : 0u;
-                const bool alive = run_leaf(T, k * NB1 + nb0, sp, pe, f, a);
-                const uint32_t out = encode_post(T, f, a, alive);
-                uint32_t packed;
-                if (out >= S * NB1) {
-                    packed = pack_absolute(out, NB1);               // skip / poison
-                } else if (a.sensitive) {
-                    packed = kPkSensitive;                          // row needs one simulation per bit count
-                    atomicOr(&s_sensitive, 1u);
-                } else if (a.reset_seen) {
-                    packed = pack_absolute(out, NB1);               // bit count restarted inside the span
-                } else {
-                    const uint32_t ocur = out / NB1;
-                    const uint32_t nbo = out - ocur * NB1;
-                    const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
-                    packed = ocur | (delta << 8) | kPkRelative;     // relative: nb + delta (saturating)
-                }
-                res[l * nsim + 2 * k + cls] = packed;
-                if (cls == 0 && !a.msgc_seen && !a.overflow) {
-                    // no dependence on the bit count at all: both classes share the run
-                    res[l * nsim + 2 * k + 1] = packed;
-                    break;
-                }
-            }
+        const uint32_t cls = task & 1u, pair = task >> 1;
+        const uint32_t k = pair / nu, up = pair - k * nu;
+        const uint32_t l = uniq[1 + up];
+        const uint32_t nb0 = cls ? max_bits : 0u;
+        const bool alive = run_leaf(T, k * NB1 + nb0, span_of(edges, first + l), resume[l], f, a);
+        const uint32_t out = encode_post(T, f, a, alive);
+        uint32_t packed;
+        if (out >= S * NB1) {
+            packed = pack_absolute(out, NB1);                   // skip / poison
+        } else if (a.sensitive) {
+            packed = kPkSensitive;                              // row needs one simulation per bit count
+        } else if (a.reset_seen) {
+            packed = pack_absolute(out, NB1);                   // bit count restarted inside the span
+        } else {
+            const uint32_t ocur = out / NB1;
+            const uint32_t nbo = out - ocur * NB1;
+            const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
+            packed = ocur | (delta << 8) | kPkRelative;         // relative: nb + delta (saturating)
+        }
+        // no dependence on the bit count at all: class "all bits" takes the "few bits" result
+        if (cls == 0 && !a.msgc_seen && !a.overflow) packed |= kPkShared;
+        res[l * nsim + 2 * k + cls] = packed;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nu * S; e += blockDim.x) {
+        const uint32_t up = e / S, k = e - up * S;
+        uint32_t *r = res + (uint32_t)uniq[1 + up] * nsim + 2 * k;
+        const uint32_t p0 = r[0];
+        if (p0 & kPkShared) {
+            r[0] = p0 & ~kPkShared;
+            r[1] = p0 & ~kPkShared;
         }
     }
     __syncthreads();
@@ -591,26 +618,32 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
     __syncthreads();
 }
 
-// Phase B: expand the packed results into the tables tab[l * D + d].  Work
-// item = (leaf, state row); a lane fills the row's NB1 entries.
+// Phase B: tables.  Leaves with the same (level, length) share their normal
+// rows, so a dense table tab[l * D + code] is built for the representatives
+// only (a handful per block); the two skip entries are per leaf.  One step of
+// a walk through leaf l is then   code < S*NB1 ? tab[rep[l] * D + code]
+//                                               : skip[l][code - S*NB1]   (poison stays).
 __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint16_t *tab,
-                             const uint32_t *res, const uint64_t *resume) {
+                             const uint32_t *res, const uint64_t *resume, const uint16_t *rep,
+                             uint16_t (*skip)[2]) {
     const uint32_t S = T.S, NB1 = T.NB1, D = T.D, max_bits = T.max_bits;
     const uint32_t nsim = 2 * S + 2;
-    const uint32_t nrow = count * (S + 1);
-    for (uint32_t item = threadIdx.x; item < nrow; item += blockDim.x) {
-        const uint32_t l = item / (S + 1), cur = item - l * (S + 1);
-        uint16_t *row = tab + l * D;
+    const uint32_t SNB = S * NB1;
+    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+        skip[l][0] = (uint16_t)(res[l * nsim + 2 * S] & 0xffffu);
+        skip[l][1] = (uint16_t)(res[l * nsim + 2 * S + 1] & 0xffffu);
+    }
+    for (uint32_t l0 = 0; l0 < count; l0 += 64) {
+      // representatives of this group of 64 leaves, as a wave-uniform bit mask
+      const uint32_t lane = threadIdx.x & 63u;
+      uint64_t reps = __ballot(l0 + lane < count && rep[l0 + lane] == l0 + lane);
+      while (reps) {
+        const uint32_t l = l0 + (uint32_t)__ffsll((long long)reps) - 1u;
+        reps &= reps - 1;
         const uint32_t *r = res + l * nsim;
-        if (cur == S) {
-            row[S * NB1] = (uint16_t)(r[2 * S] & 0xffffu);
-            row[S * NB1 + 1] = (uint16_t)(r[2 * S + 1] & 0xffffu);
-            row[S * NB1 + 2] = (uint16_t)(S * NB1 + 2);         // poison stays poison
-            continue;
-        }
-        const uint32_t pk_lo = r[2 * cur], pk_hi = r[2 * cur + 1];
-        for (uint32_t nb = 0; nb < NB1; ++nb) {
-            const uint32_t pk = nb >= max_bits ? pk_hi : pk_lo;
+        for (uint32_t e = threadIdx.x; e < SNB; e += blockDim.x) {
+            const uint32_t cur = e / NB1, nb = e - cur * NB1;
+            const uint32_t pk = r[2 * cur + (nb >= max_bits ? 1u : 0u)];
             uint32_t out;
             if (pk & kPkAbsolute) {
                 out = pk & 0xffffu;
@@ -622,14 +655,21 @@ __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t firs
                 // exact per-count simulation (rare)
                 PSim f;
                 Acc a;
-                const uint64_t i = first + l;
-                const bool alive = run_leaf(T, cur * NB1 + nb, span_of(edges, i), resume[l], f, a);
+                const bool alive = run_leaf(T, e, span_of(edges, first + l), resume[l], f, a);
                 out = encode_post(T, f, a, alive);
             }
-            row[cur * NB1 + nb] = (uint16_t)out;
+            tab[l * D + e] = (uint16_t)out;
         }
+      }
     }
     __syncthreads();
+}
+
+// one leaf applied to an abstract state code
+__device__ __forceinline__ uint32_t leaf_step(const uint16_t *tab, const uint16_t *rep, const uint16_t (*skip)[2],
+                                              uint32_t D, uint32_t SNB, uint32_t l, uint32_t s) {
+    if (s < SNB) return tab[(uint32_t)rep[l] * D + s];
+    return s >= SNB + 2 ? s : skip[l][s - SNB];
 }
 
 __device__ __forceinline__ void locate_block(const ScanParams &sp, uint32_t gb, uint32_t &cap, uint32_t &lb) {
@@ -714,31 +754,36 @@ static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S) {
 }
 
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
-__device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t count) {
+__device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
+                               const uint16_t (*skip)[2]) {
     const uint32_t nch = (count + kChunk - 1) / kChunk;
-    for (uint32_t item = threadIdx.x; item < nch * D; item += blockDim.x) {
-        const uint32_t c = item / D, d = item - c * D;
-        const uint32_t l1 = min((c + 1) * kChunk, count);
-        uint32_t s = d;
-        for (uint32_t l = c * kChunk; l < l1; ++l) s = b.tab[l * D + s];
-        b.ctab[c * D + d] = (uint16_t)s;
-    }
-    __syncthreads();
-}
-
-// The same without materialised leaf tables: every (chunk, state) walks the
-// packed class results directly.  Valid when no row of the block is
-// bit-count sensitive.
-__device__ void compose_chunks_packed(const LTab &T, const BlockLds &b, uint32_t count) {
-    const uint32_t S = T.S, NB1 = T.NB1, D = T.D, max_bits = T.max_bits;
-    const uint32_t nsim = 2 * S + 2;
-    const uint32_t nch = (count + kChunk - 1) / kChunk;
-    for (uint32_t item = threadIdx.x; item < nch * D; item += blockDim.x) {
-        const uint32_t c = item / D, d = item - c * D;
-        const uint32_t l1 = min((c + 1) * kChunk, count);
-        AState st = a_decode(d, NB1);
-        for (uint32_t l = c * kChunk; l < l1; ++l) a_apply(b.res + l * nsim, st, S, NB1, max_bits);
-        b.ctab[c * D + d] = (uint16_t)(st.cur * NB1 + st.nb);
+    const uint32_t nitem = nch * D;
+    // An item is a chain of up to 16 dependent LDS reads; a lane walks kIlp
+    // independent items side by side so that their latencies overlap.
+    constexpr int kIlp = 5;
+    for (uint32_t base = threadIdx.x; base < nitem; base += blockDim.x * kIlp) {
+        uint32_t st[kIlp], l0[kIlp], l1[kIlp];
+#pragma unroll
+        for (int j = 0; j < kIlp; ++j) {
+            const uint32_t item = base + j * blockDim.x;
+            const uint32_t it = item < nitem ? item : 0u;
+            const uint32_t c = it / D;
+            st[j] = it - c * D;
+            l0[j] = c * kChunk;
+            l1[j] = item < nitem ? min((c + 1) * kChunk, count) : l0[j];
+        }
+        for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
+#pragma unroll
+            for (int j = 0; j < kIlp; ++j) {
+                const uint32_t l = l0[j] + step;
+                if (l < l1[j]) st[j] = leaf_step(b.tab, rep, skip, D, SNB, l, st[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kIlp; ++j) {
+            const uint32_t item = base + j * blockDim.x;
+            if (item < nitem) b.ctab[item] = (uint16_t)st[j];
+        }
     }
     __syncthreads();
 }
@@ -800,10 +845,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
-    if (threadIdx.x == 0) {
-        s_nuniq = 0;
-        s_sensitive = 0;
-    }
+    __shared__ uint16_t s_skip[256][2];
+    if (threadIdx.x == 0) s_nuniq = 0;
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
@@ -827,14 +870,12 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             const uint32_t nsim = 2 * T.S + 2;
             uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
             for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
+            uint16_t *rdst = sp.leaf_rep + (e0 + cap + first);
+            for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) rdst[l] = s_rep[l];
         }
-        const bool sensitive = s_sensitive != 0;
-        __syncthreads();
-        if (threadIdx.x == 0) s_sensitive = 0;
-        if (sensitive) block_expand(T, edges, first, count, b.tab, b.res, s_resume);
+        block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        if (sensitive) compose_chunks(b, D, count);
-        else compose_chunks_packed(T, b, count);
+        compose_chunks(b, D, T.S * T.NB1, count, s_rep, s_skip);
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;
@@ -968,7 +1009,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
     __shared__ uint16_t cin[32];
-    if (threadIdx.x == 0) s_sensitive = 0;
+    __shared__ uint16_t s_rep[256];
+    __shared__ uint16_t s_skip[256][2];
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
@@ -989,25 +1031,17 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             {
                 const uint32_t nsim = 2 * T.S + 2;
                 const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
-                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) {
-                    const uint32_t v = src[i];
-                    b.res[i] = v;
-                    if (!(v & (kPkAbsolute | kPkRelative))) atomicOr(&s_sensitive, 1u);
-                }
+                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) b.res[i] = src[i];
+                const uint16_t *rsrc = sp.leaf_rep + (e0 + cap + first);
                 for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
                     s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
+                    s_rep[l] = rsrc[l];
                 }
             }
             __syncthreads();
-            const bool sensitive = s_sensitive != 0;
-            __syncthreads();
-            if (threadIdx.x == 0) s_sensitive = 0;
-            if (sensitive) {
-                block_expand(T, edges, first, count, b.tab, b.res, s_resume);
-                compose_chunks(b, D, count);
-            } else {
-                compose_chunks_packed(T, b, count);
-            }
+            const uint32_t SNB = T.S * T.NB1;
+            block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
+            compose_chunks(b, D, SNB, count, s_rep, s_skip);
             const uint32_t nch = (count + kChunk - 1) / kChunk;
             if (threadIdx.x == 0) {             // state entering each chunk
                 uint32_t s = sp.block_in[w];
@@ -1020,19 +1054,10 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             if (threadIdx.x < nch) {            // state entering each leaf
                 const uint32_t c = threadIdx.x;
                 const uint32_t l1 = min((c + 1) * kChunk, count);
-                if (sensitive) {
-                    uint32_t s = cin[c];
-                    for (uint32_t l = c * kChunk; l < l1; ++l) {
-                        pre[l] = (uint16_t)s;
-                        s = b.tab[l * D + s];
-                    }
-                } else {
-                    const uint32_t nsim = 2 * T.S + 2;
-                    AState st = a_decode(cin[c], T.NB1);
-                    for (uint32_t l = c * kChunk; l < l1; ++l) {
-                        pre[l] = (uint16_t)(st.cur * T.NB1 + st.nb);
-                        a_apply(b.res + l * nsim, st, T.S, T.NB1, T.max_bits);
-                    }
+                uint32_t s = cin[c];
+                for (uint32_t l = c * kChunk; l < l1; ++l) {
+                    pre[l] = (uint16_t)s;
+                    s = leaf_step(b.tab, s_rep, s_skip, D, SNB, l, s);
                 }
             }
             __syncthreads();
@@ -1408,6 +1433,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.cap_base = a.cap_base;
     sp.fin_blocks_cap = a.fin_blocks_cap;
     sp.leaf_res = a.leaf_res;
+    sp.leaf_rep = a.leaf_rep;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;

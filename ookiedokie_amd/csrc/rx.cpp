@@ -278,6 +278,7 @@ struct ookd_rx {
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab, d_block_in;
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
+    DevBuf<uint16_t> d_leaf_rep;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
@@ -329,6 +330,7 @@ struct ookd_rx {
         d_debug.release();
         d_block_tab.release();
         d_leaf_res.release();
+        d_leaf_rep.release();
         d_cap_group_off.release();
         d_group_tab.release();
         d_group_in.release();
@@ -581,6 +583,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
     a.leaf_res = d_leaf_res.p;
+    a.leaf_rep = d_leaf_rep.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
     a.group_in = d_group_in.p;
@@ -943,6 +946,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 rc |= rx->d_cap_end.alloc(caps + 8);
             }
             rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
+            rc |= rx->d_leaf_rep.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
             rc |= rx->d_cap_block_off.alloc(caps + 1);
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
