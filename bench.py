@@ -71,11 +71,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    ndev = torch.cuda.device_count()
+    shared_gpu = local_rank >= ndev         # rehearsal only: more ranks than GPUs on this box
+    local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu or ndev < world:
+            dist.init_process_group("gloo")         # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ok.lib()
     n = args.samples
@@ -114,7 +120,8 @@ def main():
     elapsed = time.perf_counter() - t0
     res = rx.result()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
