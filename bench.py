@@ -85,8 +85,8 @@ def main():
 
     ok.lib()
     n = args.samples
-    flt = ok.Filter.load(golden("filters", args.filter))
-    dev = ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // flt.total_decimation)
+    flt = ok.Filter.load(golden("filters", args.filter)) if args.filter != "none" else None
+    dev = ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // (flt.total_decimation if flt else 1))
 
     # ---- synthetic capture generated directly in HBM ----------------------------------
     syn = ok.Synth(dev, n, seed=SEED_BASE + 2 + rank, sample_rate=RATE)
@@ -200,8 +200,8 @@ def main():
         O.build()
         m = min(CPU_SLICE, n)
         iq = capture[:2 * m].cpu().numpy()
-        ofir = O.load_filter_json(golden("filters", args.filter))
-        odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE // flt.total_decimation)
+        ofir = O.load_filter_json(golden("filters", args.filter)) if flt else None
+        odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE // (flt.total_decimation if flt else 1))
         t1 = time.perf_counter()
         want = O.rx(iq, ofir, THRESHOLD, odev, SPB)
         cpu_s = time.perf_counter() - t1

@@ -726,46 +726,57 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const FrontParams p, u
 // front end, no filter ("-F none", ookiedokie.c:260-263): threshold the
 // unpacked samples directly.  16 B per lane loads; a wave covers 256 samples.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nofir_bits_kernel(const FrontParams p) {
+// One wavefront = 1024 samples (16 per lane, four 16 B loads issued up
+// front), same tile / tile-info convention as the 1-stage FIR kernel.
+__global__ __launch_bounds__(64) void nofir_bits_kernel(const FrontParams p) {
+    const uint32_t tid = threadIdx.x;
     const uint32_t cap = blockIdx.y;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kWaveTile;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
     uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     float2 *fout = p.fir_out ? reinterpret_cast<float2 *>(p.fir_out) + (uint64_t)cap * p.n_out : nullptr;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const uint64_t nquads = (p.words_per_cap * 64) >> 2;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    // every lane of a wave runs the same number of iterations (nquads is a
-    // multiple of 64 because words_per_cap is a multiple of 64 words)
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nquads; v += stride) {
-        const uint64_t n = 4 * v;
-        float2 s[4];
-        if (aligned16 && n + 3 < p.n_valid) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(src + n);
-            s[0] = unpack_iq(q.x);
-            s[1] = unpack_iq(q.y);
-            s[2] = unpack_iq(q.z);
-            s[3] = unpack_iq(q.w);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] = fetch_sample(p, src, nullptr, (int64_t)(n + i));
-        }
-        uint32_t nib = 0;
+    const uint64_t o0 = t0 + 16ull * tid;          // lane owns samples o0 .. o0+15
+    uint32_t raw[16];
+    if (aligned16 && t0 + kWaveTile <= p.n_valid) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src + o0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool valid = n + i < p.n_out;
-            nib |= ((valid && power_ref(s[i].x, s[i].y) >= p.p_star) ? 1u : 0u) << i;
-            if (fout && valid) fout[n + i] = s[i];
+            const uint4 q = s4[i];
+            raw[4 * i] = q.x;
+            raw[4 * i + 1] = q.y;
+            raw[4 * i + 2] = q.z;
+            raw[4 * i + 3] = q.w;
         }
-        const uint32_t l = lane_id();
-        uint32_t half = nib << (4u * (l & 7u));
-        half |= __shfl_xor(half, 1);
-        half |= __shfl_xor(half, 2);
-        half |= __shfl_xor(half, 4);            // lanes 8g..8g+7 hold samples 32g..32g+31
-        const uint32_t hi = __shfl_down(half, 8);
-        if ((l & 15u) == 0) {
-            words[(n >> 6)] = (uint64_t)half | ((uint64_t)hi << 32);
-        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) raw[i] = fetch_raw(p, src, (int64_t)(o0 + i));
     }
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float2 v = unpack_iq(raw[i]);
+        const bool valid = o0 + i < p.n_out;
+        mask |= ((valid && power_ref(v.x, v.y) >= p.p_star) ? 1u : 0u) << i;
+        if (fout && valid) fout[o0 + i] = v;
+    }
+    {
+        // level changes inside the tile (see fir1_bits_kernel)
+        const uint32_t keep = o0 >= p.n_out ? 0u : (o0 + 16 <= p.n_out ? 16u : (uint32_t)(p.n_out - o0));
+        const uint32_t prev_top = __shfl_up(mask >> 15, 1);
+        uint32_t ch = (mask ^ (mask << 1)) & 0xfffeu;
+        if (tid != 0) ch |= (mask ^ prev_top) & 1u;
+        ch &= (1u << keep) - 1u;
+        uint32_t cnt = __popc(ch);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> 15) & 1u), 63);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31);
+    }
+    const uint32_t pair = mask | (__shfl_xor(mask, 1) << 16);      // valid on even lanes
+    const uint32_t hi = __shfl_xor(pair, 2);
+    if ((tid & 3u) == 0) words[(t0 >> 6) + (tid >> 2)] = (uint64_t)pair | ((uint64_t)hi << 32);
 }
 
 // ---------------------------------------------------------------------------
@@ -922,7 +933,7 @@ static bool use_fir2(const FrontParams &p) {
 }
 
 uint64_t front_wave_tiles(const FrontParams &p) {
-    if (use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * kFirWaves;
+    if (p.num_stages == 0 || use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * kFirWaves;
     if (use_fir2(p)) {
         const uint64_t per_wg = (uint64_t)kFir2Waves * Fir2Dec4::F;
         return ((p.n_out + per_wg - 1) / per_wg) * kFir2Waves;
@@ -931,7 +942,7 @@ uint64_t front_wave_tiles(const FrontParams &p) {
 }
 
 uint32_t front_tile_bits(const FrontParams &p) {
-    if (use_fir1(p)) return kWaveTile;
+    if (p.num_stages == 0 || use_fir1(p)) return kWaveTile;
     if (use_fir2(p)) return Fir2Dec4::F;
     return 0;
 }
@@ -939,10 +950,9 @@ uint32_t front_tile_bits(const FrontParams &p) {
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream) {
     if (p.n_out == 0) return hipSuccess;
     if (p.num_stages == 0) {
-        const uint64_t nquads = (p.words_per_cap * 64) >> 2;
-        uint64_t blocks = (nquads + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)blocks, num_captures), dim3(256), 0, stream, p);
+        // whole 4096-sample blocks, so every bit word of the capture is written
+        const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * kFirWaves;
+        hipLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)tiles, num_captures), dim3(64), 0, stream, p);
         return hipGetLastError();
     }
     if (use_fir1(p)) {
