@@ -453,9 +453,9 @@ struct ScanParams {
     uint32_t total_blocks_cap;
     uint32_t leaf_block;        // leaves per block (<= 256)
     uint32_t *fin_off;          // [captures + 1] prefix of finish-block counts
-    uint4 *fsum;                // [finish blocks] appends, outputs, errors, last epoch start + 1
-    uint4 *fbase;               // [finish blocks] exclusive prefixes + epoch entering the block
-    unsigned long long *cap_base;   // [captures][2] message / error slot bases
+    unsigned long long *fagg;   // [finish blocks][4] appends, outputs, errors, last epoch start + 1, each | stamp << 32
+    uint32_t *fin_ticket;       // next finish block to hand out (zero at launch)
+    uint32_t run_stamp;         // != 0, different from the previous launch's
     uint32_t fin_blocks_cap;
     uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
     uint16_t *leaf_rep;         // [edges + captures] block-local index of the leaf whose normal rows this one shares
@@ -1219,47 +1219,28 @@ __device__ void fin_block_scan(const ScanParams &sp, uint32_t cap, uint32_t fb, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kFinBlock) void fin_sum_kernel(ScanParams sp) {
-    __shared__ uint32_t sh[4][kFinBlock];
-    if (*sp.fallback) return;
-    const uint32_t total = sp.fin_off[sp.f.num_captures];
-    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
-        uint32_t cap, fb;
-        locate_fin(sp, g, cap, fb);
-        FinLeaf L;
-        fin_block_scan(sp, cap, fb, L, sh);
-        if (threadIdx.x == 0) sp.fsum[g] = make_uint4(L.a_tot, L.o_tot, L.e_tot, L.r_tot);
-    }
+// Finish blocks are numbered capture-major, so "everything before block g" is
+// a plain prefix: outputs / errors over ALL earlier blocks give the global
+// message / error slot (deterministic order, no atomics), appends and the
+// epoch only over the earlier blocks of the same capture.
+//
+// One pass: a workgroup takes a ticket g, scans its 1024 leaves, publishes the
+// block aggregate, then adds up its predecessors' aggregates (they took their
+// tickets earlier, publish before they wait for anything, so they arrive) and
+// writes.  An aggregate is four 64-bit words  value | run stamp << 32: a reader
+// simply re-reads a word (device-scope atomic load, past the L1) until it
+// carries this run's stamp.
+
+__device__ __forceinline__ void agg_store(unsigned long long *slot, uint32_t v, uint32_t stamp) {
+    __hip_atomic_store(slot, (unsigned long long)v | ((unsigned long long)stamp << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// per capture: exclusive scan over its finish blocks; message / error slots
-__global__ __launch_bounds__(kScanThreads) void fin_scan_kernel(ScanParams sp) {
-    __shared__ unsigned long long base_msg, base_err;
-    if (*sp.fallback) return;
-    const uint32_t max_bits = sp.f.tables->max_bits;
-    for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
-        const uint32_t f0 = sp.fin_off[cap], f1 = sp.fin_off[cap + 1];
-        // a capture has a handful of finish blocks (1024 leaves each): one lane walks them
-        if (threadIdx.x == 0) {
-            const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
-            uint32_t a = nb0, o = 0, e = 0, epoch = 0;
-            for (uint32_t g = f0; g < f1; ++g) {
-                const uint4 s = sp.fsum[g];
-                sp.fbase[g] = make_uint4(a, o, e, epoch);
-                if (s.w) epoch = a + s.w - 1;
-                a += s.x;
-                o += s.y;
-                e += s.z;
-            }
-            uint64_t e0;
-            const uint64_t ne = cap_edges(sp.f, cap, e0);
-            if ((uint64_t)a > 2 * (ne + 1) + 512) atomicOr(sp.fallback, (uint32_t)kFbPool);
-            base_msg = atomicAdd((unsigned long long *)&sp.f.totals[0], (unsigned long long)o);
-            base_err = atomicAdd((unsigned long long *)&sp.f.totals[1], (unsigned long long)e);
-            sp.cap_base[2 * cap] = base_msg;
-            sp.cap_base[2 * cap + 1] = base_err;
-        }
-        __syncthreads();
+__device__ __forceinline__ uint32_t agg_load(const unsigned long long *slot, uint32_t stamp) {
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) == stamp) return (uint32_t)v;
+        __builtin_amdgcn_s_sleep(2);
     }
 }
 
@@ -1270,41 +1251,99 @@ __device__ __forceinline__ uint64_t pool_start(uint64_t e0, uint32_t cap) {
 // append values by ordinal, error list, message descriptors (sample, epoch, count)
 __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
     __shared__ uint32_t sh[4][kFinBlock];
-    if (*sp.fallback) return;
+    __shared__ uint32_t s_g;
+    __shared__ uint32_t s_acc[4];       // appends (same capture), outputs, errors (all), last block with a reset + 1
+    // bits other kernels may have raised are final by now; kFbPool is raised in here and must
+    // not make a later workgroup skip its publication
+    if (*sp.fallback & ~(uint32_t)kFbPool) return;
     const uint32_t total = sp.fin_off[sp.f.num_captures];
     const uint32_t max_bits = sp.f.tables->max_bits;
-    for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+    const uint32_t stamp = sp.run_stamp;
+    const uint32_t tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) {
+            s_g = atomicAdd(sp.fin_ticket, 1u);
+            s_acc[0] = s_acc[1] = s_acc[2] = s_acc[3] = 0;
+        }
+        __syncthreads();
+        const uint32_t g = s_g;
+        if (g >= total) break;
         uint32_t cap, fb;
         locate_fin(sp, g, cap, fb);
         FinLeaf L;
         fin_block_scan(sp, cap, fb, L, sh);
+        if (tid == 0) {
+            unsigned long long *slot = sp.fagg + 4 * (size_t)g;
+            agg_store(slot + 0, L.a_tot, stamp);
+            agg_store(slot + 1, L.o_tot, stamp);
+            agg_store(slot + 2, L.e_tot, stamp);
+            agg_store(slot + 3, L.r_tot, stamp);
+        }
+        // ---- predecessors -----------------------------------------------------------------
+        const uint32_t g0 = sp.fin_off[cap];
+        {
+            uint32_t a = 0, o = 0, e = 0, last = 0;
+            for (uint32_t j = tid; j < g; j += blockDim.x) {
+                const unsigned long long *slot = sp.fagg + 4 * (size_t)j;
+                o += agg_load(slot + 1, stamp);
+                e += agg_load(slot + 2, stamp);
+                if (j >= g0) {
+                    a += agg_load(slot + 0, stamp);
+                    if (agg_load(slot + 3, stamp)) last = j + 1;
+                }
+            }
+            if (a) atomicAdd(&s_acc[0], a);
+            if (o) atomicAdd(&s_acc[1], o);
+            if (e) atomicAdd(&s_acc[2], e);
+            if (last) atomicMax(&s_acc[3], last);
+        }
+        __syncthreads();
+        const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
+        const uint32_t a_before = nb0 + s_acc[0], o_before = s_acc[1], e_before = s_acc[2];
+        const uint32_t jr = s_acc[3];           // block jr-1 holds the latest reset before this block
+        __syncthreads();
+        uint32_t epoch_in = 0;
+        if (jr) {
+            // appends of this capture before block jr-1, then that block's last epoch start
+            if (tid == 0) s_acc[0] = 0;
+            __syncthreads();
+            uint32_t a = 0;
+            for (uint32_t j = g0 + tid; j + 1 < jr; j += blockDim.x) a += agg_load(sp.fagg + 4 * (size_t)j, stamp);
+            if (a) atomicAdd(&s_acc[0], a);
+            __syncthreads();
+            epoch_in = nb0 + s_acc[0] + agg_load(sp.fagg + 4 * (size_t)(jr - 1) + 3, stamp) - 1;
+            __syncthreads();
+        }
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const bool last_of_cap = g + 1 == sp.fin_off[cap + 1];
+        if (tid == 0) {
+            if (last_of_cap && (uint64_t)(a_before + L.a_tot) > 2 * (ne + 1) + 512) atomicOr(sp.fallback, (uint32_t)kFbPool);
+            if (g + 1 == total) {
+                sp.f.totals[0] = (uint64_t)o_before + L.o_tot;
+                sp.f.totals[1] = (uint64_t)e_before + L.e_tot;
+            }
+        }
         const uint64_t pool0 = pool_start(e0, cap);
         if (pool0 + 2 * (ne + 1) + 512 > sp.app_capacity) {
-            if (threadIdx.x == 0) atomicOr(sp.fallback, (uint32_t)kFbPool);
+            if (tid == 0) atomicOr(sp.fallback, (uint32_t)kFbPool);
             continue;
         }
         uint8_t *vals = sp.app_vals + pool0;
-        const uint4 base = sp.fbase[g];
-        const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
-        if (fb == 0 && threadIdx.x < nb0) {
-            const uint32_t t = threadIdx.x;
-            vals[t] = (uint8_t)((sp.first.data[t >> 6] >> (t & 63)) & 1ull);
-        }
-        if (fb == 0 && threadIdx.x == 0 && nb0 > (uint32_t)kFinBlock) atomicOr(sp.fallback, (uint32_t)kFbPool);
+        if (fb == 0 && tid < nb0) vals[tid] = (uint8_t)((sp.first.data[tid >> 6] >> (tid & 63)) & 1ull);
+        if (fb == 0 && tid == 0 && nb0 > (uint32_t)kFinBlock) atomicOr(sp.fallback, (uint32_t)kFbPool);
         if (!L.have) continue;
-        const uint32_t ai = base.x + L.a_in;
-        const uint32_t epoch = L.r_in ? base.x + L.r_in - 1 : base.w;
+        const uint32_t ai = a_before + L.a_in;
+        const uint32_t epoch = L.r_in ? a_before + L.r_in - 1 : epoch_in;
         for (uint32_t j = 0; j < L.ev.napp && j < 32; ++j) vals[ai + j] = (uint8_t)((L.ev.appvals >> j) & 1u);
         if (L.ev.nerr) {
-            const uint64_t slot = sp.cap_base[2 * cap + 1] + base.z + L.e_in;
+            const uint64_t slot = (uint64_t)e_before + L.e_in;
             if (slot < sp.err_capacity) sp.errs[slot] = L.ev.err_pos;
         }
         for (uint32_t j = 0; j < L.ev.nout && j < 2; ++j) {
             const uint32_t ep = L.ev.out_rb[j] != 0xffu ? ai + L.ev.out_rb[j] : epoch;
             const uint32_t have = ai + L.ev.out_ab[j] - ep;
-            const uint64_t slot = sp.cap_base[2 * cap] + base.y + L.o_in + j;
+            const uint64_t slot = (uint64_t)o_before + L.o_in + j;
             if (slot < sp.f.msg_capacity) {
                 MsgDev mm;
                 mm.capture = cap;
@@ -1316,7 +1355,7 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             }
         }
         // outgoing state: the lane that owns the tail leaf
-        if ((uint64_t)fb * kFinBlock + threadIdx.x == ne) {
+        if ((uint64_t)fb * kFinBlock + tid == ne) {
             SegState so;
             so.st.cur = L.ev.end_cur;
             so.st.k = L.ev.end_k;
@@ -1428,9 +1467,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.total_blocks_cap = a.total_blocks_cap;
     sp.leaf_block = a.leaf_block;
     sp.fin_off = a.fin_off;
-    sp.fsum = reinterpret_cast<uint4 *>(a.fsum);
-    sp.fbase = reinterpret_cast<uint4 *>(a.fbase);
-    sp.cap_base = a.cap_base;
+    sp.fagg = reinterpret_cast<unsigned long long *>(a.fsum);
+    sp.fin_ticket = a.fin_ticket;
+    sp.run_stamp = a.run_stamp;
     sp.fin_blocks_cap = a.fin_blocks_cap;
     sp.leaf_res = a.leaf_res;
     sp.leaf_rep = a.leaf_rep;
@@ -1458,9 +1497,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
     hipLaunchKernelGGL(scan_blockin_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
-    hipLaunchKernelGGL(fin_sum_kernel, dim3(a.grid_blocks), dim3(kFinBlock), 0, stream, sp);
-    hipLaunchKernelGGL(fin_scan_kernel, dim3(cap_grid), dim3(kScanThreads), 0, stream, sp);
-    hipLaunchKernelGGL(fin_write_kernel, dim3(a.grid_blocks), dim3(kFinBlock), 0, stream, sp);
+    // the finish workgroups wait for each other: no more of them than fit the chip at once
+    hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
     hipLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, sp);
     return hipGetLastError();
 }

@@ -224,8 +224,9 @@ struct FsmScanArgs {
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]
-    void *fsum, *fbase;         // [fin_blocks_cap] x 16 B each
-    unsigned long long *cap_base;   // [captures * 2]
+    void *fsum;                 // [fin_blocks_cap] x 32 B: stamped block aggregates
+    uint32_t *fin_ticket;       // zero at launch
+    uint32_t run_stamp;         // != 0, changes every launch
     uint32_t fin_blocks_cap;
     uint32_t *cap_group_off;    // [captures + 1]
     uint16_t *group_tab;        // [total_blocks_cap / 16 + captures + 1][D rounded up to 8]

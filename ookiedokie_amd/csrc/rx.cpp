@@ -41,6 +41,8 @@ struct ResultHeader {
     unsigned long long recompute;
     uint32_t total_edges;
     uint32_t scan_fallback;
+    uint32_t fin_ticket;        // work counter of the scan's finish kernel
+    uint32_t pad;
 };
 
 template <typename T>
@@ -289,6 +291,7 @@ struct ookd_rx {
     DevBuf<uint64_t> d_fsum, d_fbase;       // 16 B per finish block
     DevBuf<unsigned long long> d_cap_base;
     uint32_t scan_fin_cap = 0;
+    uint32_t scan_stamp = 0;        // stamps the finish kernel's block aggregates, never 0
     DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
     Ingest ingest;                  // its pinned double buffer (lazy)
 
@@ -601,8 +604,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.fallback = &d_hdr.p->scan_fallback;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
-    a.fbase = d_fbase.p;
-    a.cap_base = d_cap_base.p;
+    a.fin_ticket = &d_hdr.p->fin_ticket;
+    if (++scan_stamp == 0) scan_stamp = 1;
+    a.run_stamp = scan_stamp;
     a.fin_blocks_cap = scan_fin_cap;
     // totals / scan_fallback are still zero from the header memset of front_and_edges
     HIPCHK(launch_fsm_scan(a, stream));
@@ -955,7 +959,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
             rc |= rx->d_fin_off.alloc(caps + 1);
-            rc |= rx->d_fsum.alloc(2 * (size_t)rx->scan_fin_cap);
+            rc |= rx->d_fsum.alloc(4 * (size_t)rx->scan_fin_cap);
+            // stamped aggregates: the stamp half of every word must start out as "no run"
+            if (rc == OOKD_OK && hipMemset(rx->d_fsum.p, 0, rx->d_fsum.n * sizeof(uint64_t)) != hipSuccess) rc = OOKD_ERR_HIP;
             rc |= rx->d_fbase.alloc(2 * (size_t)rx->scan_fin_cap);
             rc |= rx->d_cap_base.alloc(2 * caps);
         }
