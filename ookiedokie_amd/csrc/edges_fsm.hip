@@ -156,12 +156,12 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
 
 // level 3 fused with the compaction: add the group base, keep the global
 // prefix for later readers, write the positions.  A wavefront owns
-// kWriteSpan blocks, interleaved with the other wavefronts' (blocks with
+// kWriteSpan (4) blocks, interleaved with the other wavefronts' (blocks with
 // edges come in runs -- a message -- and would otherwise pile up on a few
 // waves): their counts / offsets are fetched by its first lanes in one go,
 // then only the blocks that hold edges (a minority: OOK is mostly constant
 // level) get the 64-word treatment.
-constexpr uint32_t kWriteSpan = 16;
+constexpr uint32_t kWriteSpan = 4;
 
 __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
