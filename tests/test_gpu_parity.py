@@ -280,6 +280,34 @@ def test_255_tap_filter(ok, oracle, vectors, tmp_path):
             assert (np.abs(y - want.fir) <= FIR_RTOL * np.maximum(np.abs(want.fir), scale)).all()
 
 
+# ------------------------------------------------- dense edges / tile info ----
+
+@pytest.mark.parametrize("filt", [None, "fs32_fs4", "fs128_fs16_dec4", "unity16"])
+@pytest.mark.parametrize("n", [1000, 4096 + 1024, 3 * 4096 + 257, 70000])
+def test_dense_random_levels(ok, oracle, filt, n):
+    """Samples that cross the threshold at random, every few samples: the edge
+    list (built from the per-tile change counts of the front-end kernels) must
+    be the oracle's, whatever the position of tile / block / capture ends."""
+    rng = np.random.default_rng(n + (0 if filt is None else len(filt)))
+    # runs of 1..12 samples, alternately far below and far above the threshold
+    runs = rng.integers(1, 13, size=2 * n)
+    lvl = np.repeat(np.arange(runs.size) & 1, runs)[:n]
+    iq = np.zeros(2 * n, dtype=np.int16)
+    iq[0::2] = np.where(lvl == 1, 1500, 20) + rng.integers(-15, 16, size=n)
+    iq[1::2] = rng.integers(-15, 16, size=n)
+    f = _flt(ok, filt)
+    of = _ofir(oracle, filt)
+    for spb in (512, 8192):
+        rx = ok.Receiver(f, None, max_samples=n, threshold=0.1, samples_per_buffer=spb, edge_capacity=n + 64)
+        got = rx.rx(iq)
+        want = oracle.rx(iq, of, 0.1, None, spb, want_bits=True)
+        assert (rx.bits() == want.bits).all()
+        assert list(rx.edges()) == list(edges_of(want.bits))
+        assert got.stats["num_edges"] == len(edges_of(want.bits))
+        assert rx.dig_text() == oracle.dig_text(want.bits, max(1, spb // (of.total_decimation if of else 1)))
+        rx.close()
+
+
 # ------------------------------------------------------------- guard band ----
 
 @pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
