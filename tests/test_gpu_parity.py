@@ -137,6 +137,28 @@ def test_g1_printed_text(ok, vectors):
     rx.close()
 
 
+def test_c_host_example(ok, vectors, tmp_path):
+    """The C99 host of examples/ookd_rx.c (gcc, header + .so only): backend
+    handle -> HBM capture -> fused demod -> printed text, plus --rx-rec-dig."""
+    import subprocess
+    from tests.test_host import _build_c_example
+    exe = _build_c_example(tmp_path)
+    g, iq = _g1(vectors)
+    cap = tmp_path / "g1.sc16q11"
+    iq.tofile(str(cap))
+    dig = tmp_path / "dig.csv"
+    r = subprocess.run([exe, str(cap), golden_path("devices", "p3l-nexa2012"), golden_path("filters", "fs32_fs4"),
+                        str(RATE), "csv", str(dig)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0] == "Decode Timestamp,Preamble,Unknown-1,Channel,Temperature (C),Temperature (F),Unknown-2"
+    assert [ln.split(",", 1)[1] for ln in lines[1:4]] == ["0x27,0xd5,2,21.500,70.700,0x00"] * 3
+    rx = ok.Receiver(_flt(ok, "fs32_fs4"), None, max_samples=iq.size // 2)
+    rx.rx(iq)
+    assert dig.read_text() == rx.dig_text()
+    rx.close()
+
+
 @pytest.mark.parametrize("spb", [1000, 4096, 65536])
 def test_g1_other_buffer_sizes(ok, oracle, vectors, spb):
     g, iq = _g1(vectors)

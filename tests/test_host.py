@@ -211,3 +211,32 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     assert "no CPU fallback" in str(e.value)
     with pytest.raises(ok.OokdError):
         ok.StreamFir(f, 4096)
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "ookiedokie_amd", "lib")
+    exe = str(tmp_path / "ookd_rx")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "ookd_rx.c"), "-o", exe, "-L" + libdir, "-lookiedokie_amd",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c_host_example_builds_and_fails_loudly_without_gpu(tmp_path):
+    """examples/ookd_rx.c is the C99 host INTEGRATION.md describes: it must build
+    against the header with gcc alone and, like every compute entry, refuse to
+    run without a HIP device."""
+    import subprocess
+    ok.lib()
+    exe = _build_c_example(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe, "/nonexistent.sc16q11", golden_path("devices", "p3l-nexa2012"), "none", "3000000"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
