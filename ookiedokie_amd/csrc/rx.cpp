@@ -288,8 +288,7 @@ struct ookd_rx {
     DevBuf<uint64_t> d_scan_errs;
     DevBuf<SegState> d_final_state;
     DevBuf<uint32_t> d_fin_off;
-    DevBuf<uint64_t> d_fsum, d_fbase;       // 16 B per finish block
-    DevBuf<unsigned long long> d_cap_base;
+    DevBuf<uint64_t> d_fsum;                // 32 B per finish block: stamped aggregates
     uint32_t scan_fin_cap = 0;
     uint32_t scan_stamp = 0;        // stamps the finish kernel's block aggregates, never 0
     DevBuf<int16_t> d_stage_in;     // process_host staging (lazy)
@@ -346,8 +345,6 @@ struct ookd_rx {
         d_final_state.release();
         d_fin_off.release();
         d_fsum.release();
-        d_fbase.release();
-        d_cap_base.release();
         d_stage_in.release();
         if (h_hdr) (void)hipHostFree(h_hdr);
         if (h_msgs) (void)hipHostFree(h_msgs);
@@ -738,12 +735,8 @@ int ookd_rx::fetch_results() {
         num_msgs = total;
         stats.num_messages = total;
         stats.num_errors = h_hdr->totals[1];
-        if (scan_used && run_caps > 1) {
-            // the scan emits each capture's messages contiguously and in order, but
-            // captures land in the order their workgroups finish
-            std::stable_sort(h_msgs, h_msgs + total,
-                             [](const MsgDev &x, const MsgDev &y) { return x.capture < y.capture; });
-        }
+        // (the scan's finish kernel numbers message slots capture-major, the round
+        //  form's gather does too: the list is already in capture order)
     }
     return OOKD_OK;
 }
@@ -962,8 +955,6 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_fsum.alloc(4 * (size_t)rx->scan_fin_cap);
             // stamped aggregates: the stamp half of every word must start out as "no run"
             if (rc == OOKD_OK && hipMemset(rx->d_fsum.p, 0, rx->d_fsum.n * sizeof(uint64_t)) != hipSuccess) rc = OOKD_ERR_HIP;
-            rc |= rx->d_fbase.alloc(2 * (size_t)rx->scan_fin_cap);
-            rc |= rx->d_cap_base.alloc(2 * caps);
         }
     }
     if (rc != OOKD_OK) return nullptr;
