@@ -458,7 +458,7 @@ struct ScanParams {
     uint32_t run_stamp;         // != 0, different from the previous launch's
     uint32_t fin_blocks_cap;
     uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
-    uint16_t *leaf_rep;         // [edges + captures] block-local index of the leaf whose normal rows this one shares
+    uint16_t *chunk_tab;        // [blocks][leaf_block / 16][Dp] chunk tables of the leaf kernel, reused by emit
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -753,6 +753,26 @@ static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S) {
     return off;
 }
 
+// The same step from the packed class results alone (a few dozen steps per
+// block in the emit kernel: not worth a table).
+__device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t l,
+                                                     const uint32_t *res, const uint64_t *resume, uint32_t s) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
+    const uint32_t *row = res + l * (2 * S + 2);
+    if (s >= SNB) return s >= SNB + 2 ? s : (row[2 * S + (s - SNB)] & 0xffffu);
+    const uint32_t cur = s / NB1, nb = s - cur * NB1;
+    const uint32_t pk = row[2 * cur + (nb >= T.max_bits ? 1u : 0u)];
+    if (pk & kPkAbsolute) return pk & 0xffffu;
+    if (pk & kPkRelative) {
+        const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+        return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+    }
+    PSim f;                     // row depends on the exact bit count (rare): simulate
+    Acc a;
+    const bool alive = run_leaf(T, s, span_of(edges, first + l), resume[l], f, a);
+    return encode_post(T, f, a, alive);
+}
+
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
 __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
                                const uint16_t (*skip)[2]) {
@@ -870,8 +890,6 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             const uint32_t nsim = 2 * T.S + 2;
             uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
             for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
-            uint16_t *rdst = sp.leaf_rep + (e0 + cap + first);
-            for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) rdst[l] = s_rep[l];
         }
         block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
@@ -883,11 +901,16 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             sp.f.debug[4 * gb + 2] = st3 - st2;
             sp.f.debug[4 * gb + 3] = s_uniq[0];
         }
-        // the block's table: every abstract state walks the chunk tables
+        // the block's table: every abstract state walks the chunk tables (kept for emit)
         const uint32_t nch = (count + kChunk - 1) / kChunk;
+        uint16_t *ctab_out = sp.chunk_tab + (size_t)gb * (LB / kChunk) * sp.Dp;
         for (uint32_t d = threadIdx.x; d < D; d += blockDim.x) {
             uint32_t s = d;
-            for (uint32_t c = 0; c < nch; ++c) s = b.ctab[c * D + s];
+            for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t t = b.ctab[c * D + d];
+                ctab_out[c * sp.Dp + d] = (uint16_t)t;
+                s = c == 0 ? t : b.ctab[c * D + s];
+            }
             sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
         }
         __syncthreads();
@@ -1009,8 +1032,6 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
     __shared__ uint16_t cin[32];
-    __shared__ uint16_t s_rep[256];
-    __shared__ uint16_t s_skip[256][2];
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
@@ -1032,17 +1053,21 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 const uint32_t nsim = 2 * T.S + 2;
                 const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
                 for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) b.res[i] = src[i];
-                const uint16_t *rsrc = sp.leaf_rep + (e0 + cap + first);
                 for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
                     s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
-                    s_rep[l] = rsrc[l];
                 }
             }
             __syncthreads();
-            const uint32_t SNB = T.S * T.NB1;
-            block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
-            compose_chunks(b, D, SNB, count, s_rep, s_skip);
             const uint32_t nch = (count + kChunk - 1) / kChunk;
+            {
+                // the leaf kernel's chunk tables of this block
+                const uint16_t *ctab_in = sp.chunk_tab + (size_t)w * (LB / kChunk) * sp.Dp;
+                for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) {
+                    const uint32_t c = i / D, d = i - c * D;
+                    b.ctab[i] = ctab_in[c * sp.Dp + d];
+                }
+            }
+            __syncthreads();
             if (threadIdx.x == 0) {             // state entering each chunk
                 uint32_t s = sp.block_in[w];
                 for (uint32_t c = 0; c < nch; ++c) {
@@ -1051,13 +1076,13 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 }
             }
             __syncthreads();
-            if (threadIdx.x < nch) {            // state entering each leaf
+            if (threadIdx.x < nch) {            // state entering each leaf: walk the packed rows
                 const uint32_t c = threadIdx.x;
                 const uint32_t l1 = min((c + 1) * kChunk, count);
                 uint32_t s = cin[c];
                 for (uint32_t l = c * kChunk; l < l1; ++l) {
                     pre[l] = (uint16_t)s;
-                    s = leaf_step(b.tab, s_rep, s_skip, D, SNB, l, s);
+                    s = leaf_step_packed(T, edges, first, l, b.res, s_resume, s);
                 }
             }
             __syncthreads();
@@ -1472,7 +1497,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.run_stamp = a.run_stamp;
     sp.fin_blocks_cap = a.fin_blocks_cap;
     sp.leaf_res = a.leaf_res;
-    sp.leaf_rep = a.leaf_rep;
+    sp.chunk_tab = a.chunk_tab;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;

@@ -211,7 +211,7 @@ struct FsmScanArgs {
     uint32_t grid_blocks;       // persistent workgroups for the leaf / emit kernels
     uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
     uint32_t *leaf_res;         // [edges + captures][2S+2]
-    uint16_t *leaf_rep;         // [edges + captures]
+    uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
     uint16_t *block_in;         // [total_blocks_cap]
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;

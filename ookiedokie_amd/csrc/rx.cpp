@@ -278,9 +278,8 @@ struct ookd_rx {
     FsmStateDev pending_first{};
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
-    DevBuf<uint16_t> d_block_tab, d_block_in;
+    DevBuf<uint16_t> d_block_tab, d_block_in, d_chunk_tab;
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
-    DevBuf<uint16_t> d_leaf_rep;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
@@ -331,8 +330,8 @@ struct ookd_rx {
         d_hdr.release();
         d_debug.release();
         d_block_tab.release();
+        d_chunk_tab.release();
         d_leaf_res.release();
-        d_leaf_rep.release();
         d_cap_group_off.release();
         d_group_tab.release();
         d_group_in.release();
@@ -582,8 +581,8 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.leaf_block = scan_leaf_block;
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
+    a.chunk_tab = d_chunk_tab.p;
     a.leaf_res = d_leaf_res.p;
-    a.leaf_rep = d_leaf_rep.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
     a.group_in = d_group_in.p;
@@ -935,6 +934,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
             rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
+            rc |= rx->d_chunk_tab.alloc((size_t)rx->scan_blocks_cap * (rx->scan_leaf_block / 16) * ((rx->scan_D + 7u) & ~7u) + 64);
             {
                 const size_t ngroups = rx->scan_blocks_cap / 16 + caps + 8;
                 rc |= rx->d_cap_group_off.alloc(caps + 1);
@@ -943,7 +943,6 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 rc |= rx->d_cap_end.alloc(caps + 8);
             }
             rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
-            rc |= rx->d_leaf_rep.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
             rc |= rx->d_cap_block_off.alloc(caps + 1);
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
