@@ -164,7 +164,11 @@ enum {
     OOKD_RX_NO_QUIET_SKIP = 1u << 3,
     /* Diagnostics: count the windows that took the shortcut (one atomic per
      * quiet window -- slows the front end, keep out of timed runs). */
-    OOKD_RX_COUNT_QUIET = 1u << 4
+    OOKD_RX_COUNT_QUIET = 1u << 4,
+    /* State machine scan: simulate every span instead of looking its result
+     * up in the per-device span tables built at create time (identical
+     * results; exists so the tests can run both). */
+    OOKD_RX_SCAN_SIMS = 1u << 5
 };
 
 typedef struct ookd_rx_config {

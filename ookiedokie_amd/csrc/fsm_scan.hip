@@ -33,6 +33,10 @@
 // oracle).
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <memory>
+#include <vector>
+
 namespace ookd {
 
 namespace {
@@ -61,7 +65,7 @@ struct LTab {
     uint32_t spb, decim;
 };
 
-__device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kNone : (uint32_t)v; }
+__host__ __device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kNone : (uint32_t)v; }
 
 __device__ void load_ltab(LTab &T, const FsmTablesDev *g, uint32_t spb, uint32_t decim) {
     for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxTriggers; i += blockDim.x) {
@@ -99,7 +103,7 @@ struct Acc {
     bool reset_seen, sensitive, overflow, msgc_seen;
 };
 
-__device__ __forceinline__ void acc_init(Acc &a) {
+__host__ __device__ __forceinline__ void acc_init(Acc &a) {
     a.napp = a.appvals = a.apps_at_reset = 0;
     a.nout = a.nerr = a.fires = 0;
     a.out_ab0 = a.out_ab1 = 0;
@@ -109,19 +113,19 @@ __device__ __forceinline__ void acc_init(Acc &a) {
     a.reset_seen = a.sensitive = a.overflow = a.msgc_seen = false;
 }
 
-__device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
+__host__ __device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
     const uint64_t s = (uint64_t)k + m;
     return s > kSat ? kSat : (uint32_t)s;
 }
 
-__device__ __forceinline__ void canon(const LTab &T, PSim &f) {
+__host__ __device__ __forceinline__ void canon(const LTab &T, PSim &f) {
     if (T.st[f.cur].w & 0x10000u) f.k = 0;
 }
 
 constexpr int kTrigBatch = 4;           // trigger records fetched together
 
 // state_machine.c:421-519, one evaluation
-__device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
+__host__ __device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
     const uint32_t s = f.cur;
     const uint4 srec = T.st[s];
     const uint32_t te = (srec.w >> 8) & 0xffu;
@@ -207,7 +211,7 @@ __device__ __forceinline__ int p_eval(const LTab &T, PSim &f, Acc &a, uint32_t b
 }
 
 // state_machine.c:521-539
-__device__ __forceinline__ int p_step(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
+__host__ __device__ __forceinline__ int p_step(const LTab &T, PSim &f, Acc &a, uint32_t b, uint64_t pos) {
     if (f.cur == 0) {
         f.nbits = 0;
         a.reset_seen = true;
@@ -220,7 +224,7 @@ __device__ __forceinline__ int p_step(const LTab &T, PSim &f, Acc &a, uint32_t b
 
 // evaluations until an always / timeout / msg_complete trigger fires while
 // the level stays constant (kNone = never)
-__device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &f, Acc &a) {
+__host__ __device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &f, Acc &a) {
     const uint4 srec = T.st[f.cur];
     const uint32_t te = (srec.w >> 8) & 0xffu;
     const uint32_t kto = srec.z;
@@ -254,7 +258,7 @@ __device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &f, Acc &a
     return best;
 }
 
-__device__ __forceinline__ uint64_t next_buffer_start(const LTab &T, uint64_t pos) {
+__host__ __device__ __forceinline__ uint64_t next_buffer_start(const LTab &T, uint64_t pos) {
     const uint64_t in_idx = (uint64_t)T.decim * (pos + 1) - 1;
     const uint64_t buf = in_idx / T.spb;
     const uint64_t nb = ((buf + 1) * (uint64_t)T.spb) / T.decim;
@@ -264,7 +268,7 @@ __device__ __forceinline__ uint64_t next_buffer_start(const LTab &T, uint64_t po
 // Runs `n` samples of constant level L starting at absolute position pos0,
 // then (has_edge) one sample of level !L.  Returns false when the span ends
 // inside a skipped rest-of-buffer (f.prev = the level of the error sample).
-__device__ __forceinline__ bool sim_span(const LTab &T, PSim &f, Acc &a, uint64_t pos0, uint32_t L, uint64_t n, bool has_edge) {
+__host__ __device__ __forceinline__ bool sim_span(const LTab &T, PSim &f, Acc &a, uint64_t pos0, uint32_t L, uint64_t n, bool has_edge) {
     uint64_t pos = pos0;
     const uint64_t end_const = pos0 + n;
     const uint64_t last = end_const + (has_edge ? 1 : 0);
@@ -325,8 +329,8 @@ __device__ __forceinline__ Span span_of(const uint64_t *edges, uint64_t i) {
 }
 
 // abstract codes:  cur * NB1 + nb | skip(prev 0/1) | poison
-__device__ __forceinline__ uint32_t code_skip(const LTab &T, uint32_t prev) { return T.S * T.NB1 + prev; }
-__device__ __forceinline__ uint32_t code_poison(const LTab &T) { return T.S * T.NB1 + 2; }
+__host__ __device__ __forceinline__ uint32_t code_skip(const LTab &T, uint32_t prev) { return T.S * T.NB1 + prev; }
+__host__ __device__ __forceinline__ uint32_t code_poison(const LTab &T) { return T.S * T.NB1 + 2; }
 
 // Concrete run of span sp from abstract state `code`; `resume` = first sample
 // after the buffer of the edge that precedes the span (where a skip state
@@ -340,7 +344,7 @@ struct SimRes {
     uint32_t w[12];
 };
 
-__device__ __forceinline__ SimRes sim_pack(const PSim &f, const Acc &a, bool alive) {
+__host__ __device__ __forceinline__ SimRes sim_pack(const PSim &f, const Acc &a, bool alive) {
     SimRes r;
     r.w[0] = (f.cur & 0xffu) | ((f.prev & 1u) << 8) | ((alive ? 1u : 0u) << 9) | ((a.reset_seen ? 1u : 0u) << 10) |
              ((a.sensitive ? 1u : 0u) << 11) | ((a.overflow ? 1u : 0u) << 12) | ((a.msgc_seen ? 1u : 0u) << 13);
@@ -360,7 +364,7 @@ __device__ __forceinline__ SimRes sim_pack(const PSim &f, const Acc &a, bool ali
 }
 
 // -> alive
-__device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Acc &a) {
+__host__ __device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Acc &a) {
     f.cur = r.w[0] & 0xffu;
     f.prev = (r.w[0] >> 8) & 1u;
     f.k = r.w[1];
@@ -389,7 +393,7 @@ __device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Acc &a) {
 // after the buffer of the edge that precedes the span (where a skip state
 // starts feeding samples again).  alive = false: ends inside a skip.  Must not
 // be called with the poison code.  lvl_edge = level | has_edge << 1.
-__device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t code, uint64_t pos0, uint64_t n, uint32_t lvl_edge,
+__host__ __device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t code, uint64_t pos0, uint64_t n, uint32_t lvl_edge,
                                             uint64_t resume) {
     const uint32_t NB1 = T.NB1;
     const uint32_t nstates = T.S * NB1;
@@ -427,7 +431,7 @@ __device__ __forceinline__ bool run_leaf(const LTab &T, uint32_t code, const Spa
     return sim_unpack(r, f, a);
 }
 
-__device__ __forceinline__ uint32_t encode_post(const LTab &T, const PSim &f, const Acc &a, bool alive) {
+__host__ __device__ __forceinline__ uint32_t encode_post(const LTab &T, const PSim &f, const Acc &a, bool alive) {
     if (a.overflow) return code_poison(T);
     if (!alive) return code_skip(T, f.prev);
     if (f.k != 0 && !(T.st[f.cur].w & 0x10000u)) return code_poison(T);   // counter not zeroed: not representable
@@ -459,6 +463,9 @@ struct ScanParams {
     uint32_t fin_blocks_cap;
     uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
     uint16_t *chunk_tab;        // [blocks][leaf_block / 16][Dp] chunk tables of the leaf kernel, reused by emit
+    // span tables (build_leaf_tables): packed result of a span as a function of its
+    // length, per (row, level); null = simulate
+    const uint32_t *lt_off, *lt_n0, *lt_pk;
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -497,13 +504,54 @@ constexpr uint32_t kPkSensitive = 0x40000000u;
 constexpr uint32_t kPkRelative = 0x20000000u;   // [7:0] end state, [23:8] appended bits
 constexpr uint32_t kPkShared = 0x10000000u;     // transient: class "all bits" takes this result too
 
-__device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
+__host__ __device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
     return code | ((code / NB1) << 16) | kPkAbsolute;
+}
+
+// Packed result of a simulation from a normal state (state k, bit count nb0 =
+// representative of class cls).
+__host__ __device__ __forceinline__ uint32_t pack_normal(const LTab &T, const PSim &f, const Acc &a, bool alive,
+                                                         uint32_t nb0, uint32_t cls) {
+    const uint32_t NB1 = T.NB1;
+    const uint32_t out = encode_post(T, f, a, alive);
+    uint32_t packed;
+    if (out >= T.S * NB1) {
+        packed = pack_absolute(out, NB1);                   // skip / poison
+    } else if (a.sensitive) {
+        packed = kPkSensitive;                              // row needs one simulation per bit count
+    } else if (a.reset_seen) {
+        packed = pack_absolute(out, NB1);                   // bit count restarted inside the span
+    } else {
+        const uint32_t ocur = out / NB1;
+        const uint32_t nbo = out - ocur * NB1;
+        const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
+        packed = ocur | (delta << 8) | kPkRelative;         // relative: nb + delta (saturating)
+    }
+    // no dependence on the bit count at all: class "all bits" takes the "few bits" result
+    if (cls == 0 && !a.msgc_seen && !a.overflow) packed |= kPkShared;
+    return packed;
+}
+
+// Span tables: table (row, L) -> entries [off[2*row+L], off[2*row+L+1]); entry i
+// covers span lengths n0[i] .. n0[i+1]-1 (the last one to infinity).  Rows
+// 0 .. 2S-1 = (state, class); rows 2S, 2S+1 = start in reset with previous level
+// 0 / 1 DIFFERENT from the span's level (pk 0 = position dependent, simulate).
+__device__ __forceinline__ uint32_t lt_lookup(const uint32_t *off, const uint32_t *n0, const uint32_t *pk, uint32_t row,
+                                              uint32_t L, uint32_t n) {
+    uint32_t lo = off[2 * row + L], hi = off[2 * row + L + 1];
+    if (lo >= hi) return 0u;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (n0[mid] <= n) lo = mid;
+        else hi = mid;
+    }
+    return pk[lo];
 }
 
 #define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
                            uint64_t *resume, uint16_t *rep /* [count] */, uint16_t *uniq /* [count + 1] */,
+                           const uint32_t *lt_off, const uint32_t *lt_n0, const uint32_t *lt_pk,
                            uint64_t *dbg = nullptr) {
     STAMP(0);
     const uint32_t S = T.S, NB1 = T.NB1, max_bits = T.max_bits;
@@ -533,27 +581,63 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
     }
     __syncthreads();
     STAMP(2);
-    // list of representatives, even leaves first then odd ones (lanes of a wave
-    // then share the level); position = rank in that order
-    if (threadIdx.x == 0) uniq[0] = 0;
-    __syncthreads();
-    for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
-        if (rep[l] != l) continue;
-        uint32_t rank = 0;
-        for (uint32_t m = 0; m < count; ++m) {
-            if (rep[m] != m) continue;
-            const bool before = ((m & 1u) < (l & 1u)) || (((m & 1u) == (l & 1u)) && m < l);
-            rank += before ? 1u : 0u;
+    // list of representatives, even leaves first then odd ones (neighbouring lanes
+    // then share the level); position = rank in that order, from per-wave ballots
+    {
+        __shared__ uint64_t s_mask[16][2];              // [wave][parity] representatives
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        uint32_t total[2] = {0, 0};
+        for (uint32_t l0 = 0; l0 < count; l0 += blockDim.x) {       // one pass unless count > blockDim
+            const uint32_t l = l0 + threadIdx.x;
+            const bool isrep = l < count && rep[l] == l;
+            const uint64_t me = __ballot(isrep && !(l & 1u)), mo = __ballot(isrep && (l & 1u));
+            if (lane == 0) {
+                s_mask[wave][0] = me;
+                s_mask[wave][1] = mo;
+            }
+            __syncthreads();
+            uint32_t before[2] = {0, 0}, all[2] = {0, 0};
+            for (uint32_t w = 0; w < nwaves; ++w) {
+                const uint32_t ce = (uint32_t)__popcll(s_mask[w][0]), co = (uint32_t)__popcll(s_mask[w][1]);
+                if (w < wave) {
+                    before[0] += ce;
+                    before[1] += co;
+                }
+                all[0] += ce;
+                all[1] += co;
+            }
+            __syncthreads();
+            // odd representatives come after ALL even ones of the block: they are placed in a
+            // second sweep once the even total is known (single pass when count <= blockDim)
+            if (isrep) {
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t par = l & 1u;
+                const uint32_t r = total[par] + before[par] + (uint32_t)__popcll((par ? mo : me) & below);
+                // store parity-local rank now, add the even total below
+                uniq[1 + l] = (uint16_t)r;              // scratch: slot l, compacted afterwards
+            }
+            total[0] += all[0];
+            total[1] += all[1];
         }
-        uniq[1 + rank] = (uint16_t)l;
-        atomicAdd(reinterpret_cast<uint32_t *>(&s_nuniq), 1u);
+        __syncthreads();
+        // compact: rank among even reps, or (#even reps) + rank among odd reps
+        uint16_t mine = 0xffffu;
+        uint32_t mine_rank = 0;
+        // (count <= 256 = at most one leaf per lane and pass; larger blocks loop)
+        for (uint32_t l0 = 0; l0 < count; l0 += blockDim.x) {
+            const uint32_t l = l0 + threadIdx.x;
+            const bool isrep = l < count && rep[l] == l;
+            if (isrep) {
+                mine = (uint16_t)l;
+                mine_rank = uniq[1 + l] + ((l & 1u) ? total[0] : 0u);
+            }
+            __syncthreads();
+            if (isrep) uniq[1 + mine_rank] = mine;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) uniq[0] = (uint16_t)(total[0] + total[1]);
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uniq[0] = (uint16_t)s_nuniq;
-        s_nuniq = 0;
-    }
-    __syncthreads();
     STAMP(3);
     const uint32_t nu = uniq[0];
     // Dense tasks, one per lane: (start state, distinct span, class) for the normal
@@ -561,6 +645,62 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
     // machine is busy with the instruction streams of these waves and nothing
     // else, so lanes must not idle: neighbouring lanes share the start state
     // (same triggers, mostly the same path), and both classes run side by side.
+    if (lt_off) {
+        // ---- table driven: the packed result is a step function of the span length ----------
+        // normal rows: one lane per (distinct span, state); spans too long for the
+        // tables' 32-bit lengths are simulated
+        for (uint32_t task = threadIdx.x; task < nu * S; task += blockDim.x) {
+            const uint32_t k = task / nu, up = task - k * nu;
+            const uint32_t l = uniq[1 + up];
+            const Span sp = span_of(edges, first + l);
+            uint32_t p0, p1;
+            if (sp.n <= 0xfffffff0ull) {
+                p0 = lt_lookup(lt_off, lt_n0, lt_pk, 2 * k, sp.L, (uint32_t)sp.n);
+                p1 = (p0 & kPkShared) ? p0 : lt_lookup(lt_off, lt_n0, lt_pk, 2 * k + 1, sp.L, (uint32_t)sp.n);
+            } else {
+                PSim f;
+                Acc a;
+                bool alive = run_leaf(T, k * NB1, sp, resume[l], f, a);
+                p0 = pack_normal(T, f, a, alive, 0u, 0u);
+                alive = run_leaf(T, k * NB1 + max_bits, sp, resume[l], f, a);
+                p1 = pack_normal(T, f, a, alive, max_bits, 1u);
+            }
+            res[l * nsim + 2 * k] = p0;
+            res[l * nsim + 2 * k + 1] = p1;
+        }
+        // skip rows: per leaf.  Skipping ends at `resume`; from there the machine starts
+        // in reset -- the normal row (reset, few bits) of a shorter span when the level
+        // before the skip equals the span's, a special row otherwise.
+        for (uint32_t task = threadIdx.x; task < 2 * count; task += blockDim.x) {
+            const uint32_t kk = task / count, lp = task - kk * count;
+            const uint32_t l = parity_order(lp, count);
+            const Span sp = span_of(edges, first + l);
+            const uint64_t end_const = sp.pos0 + sp.n, last = end_const + 1;
+            const uint64_t rs = resume[l];
+            uint32_t out;
+            if (rs >= last) {
+                out = S * NB1 + kk;                              // still skipping when the span ends
+            } else {
+                const uint64_t n2 = rs >= end_const ? 0 : end_const - rs;
+                uint32_t pk = 0;
+                if (n2 <= 0xfffffff0ull) {
+                    pk = lt_lookup(lt_off, lt_n0, lt_pk, kk == sp.L ? 0u : 2 * S + kk, sp.L, (uint32_t)n2);
+                }
+                if (pk & kPkAbsolute) {
+                    out = pk & 0xffffu;
+                } else if (pk & kPkRelative) {
+                    const uint32_t nbo = (pk >> 8) & 0xffffu;       // from a bit count of 0
+                    out = (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                } else {
+                    PSim f;                                         // position dependent or sensitive
+                    Acc a;
+                    const bool alive = run_leaf(T, S * NB1 + kk, sp, rs, f, a);
+                    out = encode_post(T, f, a, alive);
+                }
+            }
+            res[l * nsim + 2 * S + kk] = pack_absolute(out, NB1);
+        }
+    } else {
     const uint32_t nnorm = 2 * nu * S;
     const uint32_t ntask = nnorm + 2 * count;
     for (uint32_t task = threadIdx.x; task < ntask; task += blockDim.x) {
@@ -579,23 +719,8 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         const uint32_t l = uniq[1 + up];
         const uint32_t nb0 = cls ? max_bits : 0u;
         const bool alive = run_leaf(T, k * NB1 + nb0, span_of(edges, first + l), resume[l], f, a);
-        const uint32_t out = encode_post(T, f, a, alive);
-        uint32_t packed;
-        if (out >= S * NB1) {
-            packed = pack_absolute(out, NB1);                   // skip / poison
-        } else if (a.sensitive) {
-            packed = kPkSensitive;                              // row needs one simulation per bit count
-        } else if (a.reset_seen) {
-            packed = pack_absolute(out, NB1);                   // bit count restarted inside the span
-        } else {
-            const uint32_t ocur = out / NB1;
-            const uint32_t nbo = out - ocur * NB1;
-            const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
-            packed = ocur | (delta << 8) | kPkRelative;         // relative: nb + delta (saturating)
-        }
-        // no dependence on the bit count at all: class "all bits" takes the "few bits" result
-        if (cls == 0 && !a.msgc_seen && !a.overflow) packed |= kPkShared;
-        res[l * nsim + 2 * k + cls] = packed;
+        res[l * nsim + 2 * k + cls] = pack_normal(T, f, a, alive, nb0, cls);
+    }
     }
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < nu * S; e += blockDim.x) {
@@ -882,7 +1007,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const uint64_t st0 = __builtin_amdgcn_s_memtime();
-        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq,
+        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq, sp.lt_off, sp.lt_n0, sp.lt_pk,
                    (sp.f.debug && gb == 2) ? sp.f.debug + 40 : nullptr);
         const uint64_t st1 = __builtin_amdgcn_s_memtime();
         {
@@ -1461,6 +1586,183 @@ __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
 }
 
 // ---------------------------------------------------------------------------
+// span tables (host): the same simulator, run once per interval of span lengths
+// ---------------------------------------------------------------------------
+//
+// From a normal state the packed result of a span depends only on its level
+// and its length n.  While the level is constant the machine follows a fixed
+// trajectory of always / timeout / msg_complete firings; the edge that ends
+// the span is then judged with a counter k = n - (time of the last firing)
+// against a handful of bounds of the state it meets.  So the result is a step
+// function of n whose steps can only lie next to   firing time + bound.  Those
+// candidates are enumerated from the trajectory, the simulator -- the very
+// code the kernels run -- is evaluated at each, equal neighbours are merged,
+// and every merged interval is probed again inside; any surprise disables the
+// tables (the kernels then simulate, as they do for rows marked 0).
+
+namespace {
+
+void fill_ltab_host(LTab &T, const FsmTablesDev &g, uint32_t spb, uint32_t decim) {
+    for (uint32_t i = 0; i < (uint32_t)kMaxTriggers; ++i) {
+        T.tr[i] = make_uint4(clamp32(g.trig_kmin[i]), clamp32(g.trig_kmax[i]), g.trig_info[i], 0u);
+    }
+    for (uint32_t i = 0; i < (uint32_t)kMaxStates; ++i) {
+        uint32_t msgc = 0;
+        for (uint32_t t = g.state_tbeg[i]; t < g.state_tend[i] && t < (uint32_t)kMaxTriggers; ++t) {
+            if ((g.trig_info[t] & 0xffu) == kCondMsgComplete) msgc = 1;
+        }
+        const uint32_t row = (g.state_tbeg[i] & 0xffu) | ((g.state_tend[i] & 0xffu) << 8) |
+                             ((g.state_flags[i] & 1u) << 16) | (msgc << 17);
+        T.st[i] = make_uint4(clamp32(g.state_kmin[i]), clamp32(g.state_kmax[i]), clamp32(g.state_kto[i]), row);
+    }
+    T.max_bits = g.max_bits;
+    T.S = g.num_states;
+    T.NB1 = g.max_bits + 2;
+    T.D = g.num_states * (g.max_bits + 2) + 3;
+    T.spb = spb;
+    T.decim = decim;
+}
+
+constexpr uint64_t kProbePos = 1ull << 40;      // spans of normal rows do not depend on where they lie
+
+// packed result of a span of n constant samples + its edge; row < 2S: (state, class);
+// otherwise start in reset with previous level row - 2S != L (0 = position dependent)
+uint32_t eval_row(const LTab &T, uint32_t row, uint32_t L, uint64_t n) {
+    PSim f;
+    Acc a;
+    if (row < 2 * T.S) {
+        const uint32_t k = row >> 1, cls = row & 1u;
+        const uint32_t nb0 = cls ? T.max_bits : 0u;
+        const SimRes r = run_leaf_raw(T, k * T.NB1 + nb0, kProbePos, n, L | 2u, 0);
+        const bool alive = sim_unpack(r, f, a);
+        return pack_normal(T, f, a, alive, nb0, cls);
+    }
+    const uint32_t code = T.S * T.NB1 + (row - 2 * T.S);
+    uint32_t out[2];
+    for (int v = 0; v < 2; ++v) {
+        const uint64_t pos = kProbePos + (v ? 12345 : 0);
+        const SimRes r = run_leaf_raw(T, code, pos, n, L | 2u, pos);
+        const bool alive = sim_unpack(r, f, a);
+        // an error before the span's last sample resumes at the next buffer boundary:
+        // where that is depends on the span's position (one on the last sample ends the span skipping)
+        if (a.nerr && a.err_pos + 1 < pos + n + 1) return 0u;
+        out[v] = encode_post(T, f, a, alive);
+    }
+    return out[0] == out[1] ? pack_absolute(out[0], T.NB1) : 0u;
+}
+
+void add_candidates(std::vector<uint64_t> &c, uint64_t t, uint32_t bound) {
+    if (bound == kNone) return;
+    for (uint64_t b : {(uint64_t)bound, (uint64_t)bound / 2}) {         // reset counts twice per sample
+        for (int d = -3; d <= 3; ++d) {
+            const int64_t v = (int64_t)(t + b) + d;
+            if (v >= 0 && v <= 0xfffffff0ll) c.push_back((uint64_t)v);
+        }
+    }
+}
+
+// span lengths next to which the result of row (start state f) can change
+void row_candidates(const LTab &T, PSim f, uint32_t L, bool first_is_edge, std::vector<uint64_t> &c) {
+    Acc a;
+    acc_init(a);
+    uint64_t pos = 0;
+    for (uint64_t v = 0; v < 8; ++v) c.push_back(v);
+    if (first_is_edge) {                                // previous level != L: the first sample is an edge
+        p_step(T, f, a, L, pos);
+        f.prev = L;
+        canon(T, f);
+        pos = 1;
+    }
+    for (uint32_t it = 0; it < 4 * kMaxFires + 8; ++it) {
+        const uint4 srec = T.st[f.cur];
+        add_candidates(c, pos, 0);
+        add_candidates(c, pos, srec.x);
+        add_candidates(c, pos, srec.y);
+        add_candidates(c, pos, srec.z);
+        for (uint32_t t = srec.w & 0xffu; t < ((srec.w >> 8) & 0xffu) && t < (uint32_t)kMaxTriggers; ++t) {
+            add_candidates(c, pos, T.tr[t].x);
+            add_candidates(c, pos, T.tr[t].y);
+        }
+        const uint32_t q = p_quiet(T, f, a);
+        if (q == kNone) break;
+        const uint64_t m = f.cur == 0 ? (uint64_t)(q >> 1) : (uint64_t)q;     // as sim_span advances
+        f.k = sat_add(f.k, f.cur == 0 ? 2 * m : m);
+        if (m > 0) canon(T, f);
+        pos += m;
+        p_step(T, f, a, L, pos);
+        f.prev = L;
+        canon(T, f);
+        pos += 1;
+        if (pos > 0xfffffff0ull) break;
+    }
+}
+
+}  // namespace
+
+bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk) {
+    std::unique_ptr<LTab> Tp(new LTab());
+    LTab &T = *Tp;
+    fill_ltab_host(T, g, spb, decim);
+    const uint32_t S = T.S, rows = 2 * S + 2;
+    off.assign(2 * rows + 1, 0);
+    n0.clear();
+    pk.clear();
+    uint64_t rng = 0x9e3779b97f4a7c15ull;
+    for (uint32_t row = 0; row < rows; ++row) {
+        for (uint32_t L = 0; L < 2; ++L) {
+            off[2 * row + L] = (uint32_t)n0.size();
+            const bool special = row >= 2 * S;
+            if (special && (row - 2 * S) == L) continue;        // same level: the kernels use row 0
+            PSim f;
+            f.k = 0;
+            if (special) {
+                f.cur = 0;
+                f.nbits = 0;
+                f.prev = row - 2 * S;
+            } else {
+                f.cur = row >> 1;
+                f.nbits = (row & 1u) ? T.max_bits : 0u;
+                f.prev = L;
+            }
+            std::vector<uint64_t> c;
+            row_candidates(T, f, L, special, c);
+            c.push_back(0);
+            std::sort(c.begin(), c.end());
+            c.erase(std::unique(c.begin(), c.end()), c.end());
+            const size_t begin = n0.size();
+            uint32_t prev_pk = 0;
+            for (size_t i = 0; i < c.size(); ++i) {
+                const uint32_t v = eval_row(T, row, L, c[i]);
+                if (i == 0 || v != prev_pk) {
+                    n0.push_back((uint32_t)c[i]);
+                    pk.push_back(v);
+                    prev_pk = v;
+                }
+            }
+            // safety net: probe every interval again -- all of it when short, evenly spread
+            // points (plus both ends) when long; any surprise disables the tables
+            for (size_t i = begin; i < n0.size(); ++i) {
+                const uint64_t a = n0[i], b = i + 1 < n0.size() ? n0[i + 1] : 0xfffffff0ull;
+                const uint64_t len = b - a;
+                const uint64_t steps = len <= 512 ? len : 128;
+                for (uint64_t j = 0; j < steps; ++j) {
+                    rng ^= rng << 13;
+                    rng ^= rng >> 7;
+                    rng ^= rng << 17;
+                    const uint64_t x = len <= 512 ? a + j : a + (len / steps) * j + rng % (len / steps);
+                    if (eval_row(T, row, L, x) != pk[i]) return false;
+                }
+                if (eval_row(T, row, L, b - 1) != pk[i]) return false;
+            }
+            if (n0.size() > (1u << 16)) return false;
+        }
+    }
+    off[2 * rows] = (uint32_t)n0.size();
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------
 
@@ -1498,6 +1800,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.fin_blocks_cap = a.fin_blocks_cap;
     sp.leaf_res = a.leaf_res;
     sp.chunk_tab = a.chunk_tab;
+    sp.lt_off = a.lt_off;
+    sp.lt_n0 = a.lt_n0;
+    sp.lt_pk = a.lt_pk;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include <cstdint>
 
 namespace ookd {
@@ -212,6 +214,7 @@ struct FsmScanArgs {
     uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
     uint32_t *leaf_res;         // [edges + captures][2S+2]
     uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
+    const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     uint16_t *block_in;         // [total_blocks_cap]
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
@@ -235,6 +238,10 @@ struct FsmScanArgs {
 };
 
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);
+// Packed result of a span as a step function of its length, per (row, level)
+// (host side; false = not tabulated, the kernels simulate).
+bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk);
 uint32_t fsm_scan_fin_block();
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 

@@ -272,6 +272,7 @@ struct ookd_rx {
 
     // scan form of the state machine (fsm_scan.hip)
     bool scan_ok = false;           // device fits the scan's tables and it was not disabled
+    std::unique_ptr<FsmTablesDev> h_tables;     // host copy of the device tables
     bool scan_used = false;         // the results of the last run come from the scan
     bool scan_pending = false;      // a scan is queued; its verdict is read with the results
     bool pending_first_valid = false;
@@ -279,6 +280,7 @@ struct ookd_rx {
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab, d_block_in, d_chunk_tab;
+    DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
@@ -331,6 +333,9 @@ struct ookd_rx {
         d_debug.release();
         d_block_tab.release();
         d_chunk_tab.release();
+        d_lt_off.release();
+        d_lt_n0.release();
+        d_lt_pk.release();
         d_leaf_res.release();
         d_cap_group_off.release();
         d_group_tab.release();
@@ -582,6 +587,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
     a.chunk_tab = d_chunk_tab.p;
+    a.lt_off = d_lt_off.p;
+    a.lt_n0 = d_lt_n0.p;
+    a.lt_pk = d_lt_pk.p;
     a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
@@ -876,6 +884,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         }
         rx->have_fsm = true;
         rx->num_bits = device->num_bits;
+        rx->h_tables = std::move(t);
     }
 
     // ---- capacities -------------------------------------------------------------------
@@ -930,6 +939,37 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rx->scan_max_bits = device->num_bits;
         rx->scan_D = rx->scan_S * (device->num_bits + 2) + 3;
         rx->scan_ok = !(cfg->flags & OOKD_RX_FSM_ROUNDS) && rx->scan_D <= 384 && device->num_bits <= 254;
+        if (rx->scan_ok && !(cfg->flags & OOKD_RX_SCAN_SIMS)) {
+            // span tables: packed result of a span as a step function of its length
+            std::vector<uint32_t> off, n0, pk;
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool ok = build_leaf_tables(*rx->h_tables, cfg->samples_per_buffer, rx->total_decim, off, n0, pk);
+            if (getenv("OOKD_DEBUG")) {
+                size_t zeros = 0;
+                for (uint32_t v : pk) zeros += v == 0;
+                fprintf(stderr, "[ookd] span tables: %s, %zu intervals (%zu need simulation), %.1f ms\n",
+                        ok ? "built" : "REFUSED", n0.size(), zeros,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                if (getenv("OOKD_DEBUG")[0] == '2') {
+                    for (size_t t = 0; t + 1 < off.size(); ++t) {
+                        fprintf(stderr, "[ookd]  row %zu L %zu:", t / 2, t % 2);
+                        for (uint32_t i = off[t]; i < off[t + 1]; ++i) fprintf(stderr, " %u:%08x", n0[i], pk[i]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+            if (ok && !n0.empty()) {
+                rc |= rx->d_lt_off.alloc(off.size());
+                rc |= rx->d_lt_n0.alloc(n0.size());
+                rc |= rx->d_lt_pk.alloc(pk.size());
+                if (rc == OOKD_OK &&
+                    (hipMemcpy(rx->d_lt_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                     hipMemcpy(rx->d_lt_n0.p, n0.data(), n0.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                     hipMemcpy(rx->d_lt_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+                    rc = OOKD_ERR_HIP;
+                }
+            }
+        }
         if (rx->scan_ok) {
             rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);

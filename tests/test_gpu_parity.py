@@ -51,9 +51,9 @@ def _odev(oracle, name, rate=RATE):
 
 def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, check_fir=False,
              segment_buffers=0, rate=RATE, expect_scan=True):
-    """Runs the capture through BOTH forms of the state machine (scan of
-    per-edge transition functions; segment rounds) and checks each against
-    the oracle."""
+    """Runs the capture through every form of the state machine (scan of
+    per-edge transition functions, with span tables and with per-span
+    simulation; segment rounds) and checks each against the oracle."""
     f = _flt(ok, filt)
     of = _ofir(oracle, filt)
     dec = of.total_decimation if of else 1
@@ -62,10 +62,11 @@ def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, chec
     n = iq.size // 2
     want = oracle.rx(iq, of, thr, od, spb, want_bits=True, want_fir=check_fir)
     got = None
-    for fsm_rounds in (False, True):
+    # state machine forms: scan with span tables, scan simulating every span, rounds
+    for fsm_rounds, scan_sims in ((False, False), (False, True), (True, False)):
         rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
                          exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
-                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds)
+                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims)
         got = rx.rx(iq)
         assert got.stats["decimated_samples"] == want.decimated
         if want.decimated:
