@@ -1300,33 +1300,45 @@ __device__ __forceinline__ void locate_fin(const ScanParams &sp, uint32_t gfb, u
     fb = gfb - sp.fin_off[lo];
 }
 
-// workgroup inclusive scans over 1024 lanes: sums of (a, o, e) and max of r
+// workgroup inclusive scans over 1024 lanes: sums of (a, o, e) and max of r.
+// Shuffles inside each wavefront, one exchange of the 16 wave totals; the
+// inclusive values are also left in sh[k][lane] for the callers.
 __device__ void wg_scan4(uint32_t &a, uint32_t &o, uint32_t &e, uint32_t &r, uint32_t (*sh)[kFinBlock]) {
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t wtot[4][kFinBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t va = __shfl_up(a, d), vo = __shfl_up(o, d), ve = __shfl_up(e, d), vr = __shfl_up(r, d);
+        if ((int)lane >= d) {
+            a += va;
+            o += vo;
+            e += ve;
+            r = max(r, vr);
+        }
+    }
+    if (lane == 63) {
+        wtot[0][wave] = a;
+        wtot[1][wave] = o;
+        wtot[2][wave] = e;
+        wtot[3][wave] = r;
+    }
+    __syncthreads();
+    uint32_t pa = 0, po = 0, pe = 0, pr = 0;
+    for (uint32_t w = 0; w < wave; ++w) {
+        pa += wtot[0][w];
+        po += wtot[1][w];
+        pe += wtot[2][w];
+        pr = max(pr, wtot[3][w]);
+    }
+    a += pa;
+    o += po;
+    e += pe;
+    r = max(r, pr);
     sh[0][tid] = a;
     sh[1][tid] = o;
     sh[2][tid] = e;
     sh[3][tid] = r;
     __syncthreads();
-    for (uint32_t d = 1; d < (uint32_t)kFinBlock; d <<= 1) {
-        uint32_t va = 0, vo = 0, ve = 0, vr = 0;
-        if (tid >= d) {
-            va = sh[0][tid - d];
-            vo = sh[1][tid - d];
-            ve = sh[2][tid - d];
-            vr = sh[3][tid - d];
-        }
-        __syncthreads();
-        sh[0][tid] += va;
-        sh[1][tid] += vo;
-        sh[2][tid] += ve;
-        sh[3][tid] = max(sh[3][tid], vr);
-        __syncthreads();
-    }
-    a = sh[0][tid];
-    o = sh[1][tid];
-    e = sh[2][tid];
-    r = sh[3][tid];
 }
 
 struct FinLeaf {                // one lane = one leaf of a finish block
