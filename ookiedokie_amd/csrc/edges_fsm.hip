@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
 // level 2: one workgroup scans the group totals in place (exclusive) and
 // publishes the grand total in blk_offset[n].
 __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams p) {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t wtot[16];
     const uint32_t n = p.num_captures * p.blocks_per_cap;
     const uint32_t ng = (n + kScanGroup - 1) / kScanGroup;
     const uint32_t tid = threadIdx.x;
@@ -134,23 +134,16 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
     const uint32_t hi = min(lo + chunk, ng);
     uint32_t sum = 0;
     for (uint32_t i = lo; i < hi; ++i) sum += p.group_total[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = (tid >= d) ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum;
+    uint32_t total = 0;
+    uint32_t run = wg_inclusive_sum(sum, wtot, &total) - sum;
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t t = p.group_total[i];
         p.group_total[i] = run;
         run += t;
     }
     if (tid == 1023) {
-        p.blk_offset[n] = part[1023];
-        if ((uint64_t)part[1023] > p.edge_capacity) *p.overflow = 1;
+        p.blk_offset[n] = total;
+        if ((uint64_t)total > p.edge_capacity) *p.overflow = 1;
     }
 }
 

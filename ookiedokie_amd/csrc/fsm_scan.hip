@@ -936,7 +936,7 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint
 // prefix of per-capture block counts: scan blocks (regular leaves) and finish
 // blocks (all leaves); one workgroup
 __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp) {
-    __shared__ uint32_t part[kScanThreads], part2[kScanThreads], part3[kScanThreads];
+    __shared__ uint32_t wtot[kScanThreads / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t nc = sp.f.num_captures;
     const uint32_t chunk = (nc + kScanThreads - 1) / kScanThreads;
@@ -951,21 +951,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
         sum2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
         sum3 += (nblk + 15u) / 16u;
     }
-    part[tid] = sum;
-    part2[tid] = sum2;
-    part3[tid] = sum3;
-    __syncthreads();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0u;
-        const uint32_t v2 = tid >= d ? part2[tid - d] : 0u;
-        const uint32_t v3 = tid >= d ? part3[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        part2[tid] += v2;
-        part3[tid] += v3;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum, run2 = part2[tid] - sum2, run3 = part3[tid] - sum3;
+    uint32_t tot = 0, tot2 = 0, tot3 = 0;
+    uint32_t run = wg_inclusive_sum(sum, wtot, &tot) - sum;
+    uint32_t run2 = wg_inclusive_sum(sum2, wtot, &tot2) - sum2;
+    uint32_t run3 = wg_inclusive_sum(sum3, wtot, &tot3) - sum3;
     for (uint32_t c = lo; c < hi; ++c) {
         sp.cap_block_off[c] = run;
         sp.fin_off[c] = run2;
@@ -979,10 +968,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
         run3 += (nblk + 15u) / 16u;
     }
     if (tid == kScanThreads - 1) {
-        sp.cap_block_off[nc] = part[tid];
-        sp.fin_off[nc] = part2[tid];
-        sp.cap_group_off[nc] = part3[tid];
-        if (part[tid] > sp.total_blocks_cap || part2[tid] > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
+        sp.cap_block_off[nc] = tot;
+        sp.fin_off[nc] = tot2;
+        sp.cap_group_off[nc] = tot3;
+        if (tot > sp.total_blocks_cap || tot2 > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
     }
 }
 

@@ -245,6 +245,32 @@ bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim,
 uint32_t fsm_scan_fin_block();
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 
+// ---- workgroup inclusive sum (device code) ---------------------------------------------
+// Shuffles inside each wavefront + one exchange of the wave totals through
+// `wtot` (>= blockDim/64 entries of shared memory).  Returns the inclusive sum
+// of v over the workgroup's lanes 0..tid; *total = the sum over all lanes.
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t wg_inclusive_sum(uint32_t v, uint32_t *wtot, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if ((int)lane >= d) v += t;
+    }
+    __syncthreads();                    // wtot may still be read from a previous call
+    if (lane == 63u || threadIdx.x == blockDim.x - 1) wtot[wave] = v;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint32_t t = wtot[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    if (total) *total = all;
+    return v + before;
+}
+#endif
+
 // ---- unpack (backend rx) ----------------------------------------------------
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream);
 // ---- pack (post-filter recorder) ----------------------------------------------
