@@ -1731,6 +1731,7 @@ bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std:
             c.push_back(0);
             std::sort(c.begin(), c.end());
             c.erase(std::unique(c.begin(), c.end()), c.end());
+            if (c.size() > 20000) return false;                 // keep create time bounded: simulate instead
             const size_t begin = n0.size();
             uint32_t prev_pk = 0;
             for (size_t i = 0; i < c.size(); ++i) {
