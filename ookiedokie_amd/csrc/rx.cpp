@@ -615,8 +615,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     // totals / scan_fallback are still zero from the header memset of front_and_edges
     HIPCHK(launch_fsm_scan(a, stream));
     HIPCHK(hipEventRecord(ev[2], stream));
-    if (getenv("OOKD_DEBUG_SCAN")) HIPCHK(hipStreamSynchronize(stream));
-    if (getenv("OOKD_DEBUG_SCAN") && d_debug.p) {
+    static const char *const debug_scan = getenv("OOKD_DEBUG_SCAN");     // read once: this is the hot path
+    if (debug_scan) HIPCHK(hipStreamSynchronize(stream));
+    if (debug_scan && d_debug.p) {
         uint64_t dbg[48];
         HIPCHK(hipMemcpy(dbg, d_debug.p, sizeof(dbg), hipMemcpyDeviceToHost));
         fprintf(stderr, "[scan] block_sims phases: resume %llu gap+rep %llu uniq %llu sims %llu\n",
@@ -627,7 +628,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
                     (unsigned long long)dbg[4 * i + 2], (unsigned long long)dbg[4 * i + 3]);
     }
-    if (getenv("OOKD_DEBUG_SCAN") && getenv("OOKD_DEBUG_SCAN")[0] == '2') {
+    if (debug_scan && debug_scan[0] == '2') {
         uint32_t off[2];
         HIPCHK(hipMemcpy(off, d_cap_block_off.p, 8, hipMemcpyDeviceToHost));
         uint32_t ne32[2];
