@@ -95,19 +95,23 @@ __device__ __forceinline__ float power_ref(float re, float im) {
 // free for ds_read_b64 (32-lane halves, 64 banks), and keeps every read of
 // the unrolled body at  lane_base + compile-time immediate.
 
-__host__ __device__ __forceinline__ uint32_t slot(uint32_t j) { return j + (j >> 4); }
+// one pad slot per R samples (R = outputs per lane, a power of two)
+template <int R>
+__host__ __device__ __forceinline__ uint32_t slot(uint32_t j) { return j + j / (uint32_t)R; }
 
 // float2 slots of one wavefront's private window (kept a multiple of 2 = 16 B)
+template <int R>
 __host__ __device__ __forceinline__ uint32_t fir1_wave_slots(uint32_t Tp) {
-    return (slot(kWaveTile + Tp) + 2u) & ~1u;
+    return (slot<R>(64u * R + Tp) + 2u) & ~1u;
 }
 
 // Sequential, unfused recomputation of one output (guard-band path).
+template <int R>
 __device__ __noinline__ float2 fir1_exact_output(const float2 *lds, uint32_t j_out,
                                                  const float *taps, uint32_t ntaps) {
     float re = 0.0f, im = 0.0f;
     for (uint32_t k = 0; k < ntaps; ++k) {
-        const float2 x = lds[slot(j_out - k)];
+        const float2 x = lds[slot<R>(j_out - k)];
         const float t = taps[k];
         const float pr = t * x.x;
         const float pi = t * x.y;
@@ -149,54 +153,55 @@ __device__ __forceinline__ void cmac(v2f &acc, v2f tp, v2f x) {
 // Compile-time unrolled body of one 32-tap chunk.  Window position W
 // (newest first) feeds output r with tap kk = r - W when 0 <= kk < 32, so
 // every output receives its taps in ascending order (fir.c:313-318).
-template <bool EXACT, int W, int... Rs>
+template <bool EXACT, int R, int W, int... Rs>
 __device__ __forceinline__ void fir1_wstep(v2f *acc, const v2f *tpair, const v2f *base,
                                            std::integer_sequence<int, Rs...>) {
-    constexpr int cp = W + kTapChunk;                   // 1 .. 47
-    const v2f x = base[cp + (cp >> 4)];
+    constexpr int cp = W + kTapChunk;                   // 1 .. R + 31
+    const v2f x = base[cp + cp / R];
     ((void)((Rs - W >= 0 && Rs - W < kTapChunk)
                 ? (cmac<EXACT, ((Rs - W) & 1) != 0>(acc[Rs], tpair[((Rs - W) & 31) >> 1], x), 0)
                 : 0),
      ...);
 }
 
-template <bool EXACT, int... Ws>
+template <bool EXACT, int R, int... Ws>
 __device__ __forceinline__ void fir1_chunk(v2f *acc, const v2f *tpair, const v2f *base,
                                            std::integer_sequence<int, Ws...>) {
-    (fir1_wstep<EXACT, kFirR - 1 - Ws>(acc, tpair, base, std::make_integer_sequence<int, kFirR>{}), ...);
+    (fir1_wstep<EXACT, R, R - 1 - Ws>(acc, tpair, base, std::make_integer_sequence<int, R>{}), ...);
 }
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2s as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
 
-template <bool EXACT>
+template <bool EXACT, int R>
 __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const FrontParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-    constexpr int R = kFirR;
+    constexpr uint32_t kTile = 64u * R;                 // outputs per wavefront
+    constexpr int kRounds = (kTile + 256 + 255) / 256;  // 16 B loads per lane (taps <= 256)
     const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kWaveTile;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kTile;
     const uint32_t Tp = p.stage[0].ntaps_pad;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
-    float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots(Tp);
+    float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots<R>(Tp);
     uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
 
     // ---- load the wave's window: slot j <-> input index t0 - Tp + j ------------
-    // 1024 + Tp samples = 256 + Tp/4 vectors of 4, lane + 64*i, kept RAW in
+    // 64R + Tp samples in vectors of 4, lane + 64*i, kept RAW in
     // registers until the quiet test has decided whether they are needed.
-    const uint32_t nvec = (kWaveTile + Tp) >> 2;        // <= 320
+    const uint32_t nvec = (kTile + Tp) >> 2;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const bool interior = aligned16 && t0 >= Tp && t0 + kWaveTile <= p.n_valid;
+    const bool interior = aligned16 && t0 >= Tp && t0 + kTile <= p.n_valid;
     if (interior) {
         const uint4 *src4 = reinterpret_cast<const uint4 *>(src + (t0 - Tp));
-        uint4 q[5];
+        uint4 q[kRounds];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < kRounds; ++i) {
             const uint32_t v = tid + 64u * i;
-            q[i] = (i < 4 || v < nvec) ? src4[v] : make_uint4(0, 0, 0, 0);
+            q[i] = (64u * (i + 1) <= kTile / 4 || v < nvec) ? src4[v] : make_uint4(0, 0, 0, 0);
         }
         // ---- quiet test ----------------------------------------------------------
         // |y_re|,|y_im| <= sum|h| * max|component|, so a wave whose whole window
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         // without running the filter -- exactly what the reference computes.
         v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < kRounds; ++i) {
             mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].x), as_v2s(q[i].y)));
             mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].z), as_v2s(q[i].w)));
             mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].x), as_v2s(q[i].y)));
@@ -213,16 +218,16 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         const int L = p.quiet_lsb;
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
-            if (tid < kWaveTile / 64) words[(t0 >> 6) + tid] = 0;
-            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = 0;
+            if (tid < kTile / 64) words[(t0 >> 6) + tid] = 0;
+            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = 0;
             if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < kRounds; ++i) {
             const uint32_t v = tid + 64u * i;
-            if (i < 4 || v < nvec) {
-                float2 *dst = lds + slot(4 * v);        // 4 slots, never straddle a pad
+            if (64u * (i + 1) <= kTile / 4 || v < nvec) {
+                float2 *dst = lds + slot<R>(4 * v);        // 4 slots, never straddle a pad
                 dst[0] = unpack_iq(q[i].x);
                 dst[1] = unpack_iq(q[i].y);
                 dst[2] = unpack_iq(q[i].z);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         // first / last tiles of a capture, halo, unaligned host pointers
         for (uint32_t v = tid; v < nvec; v += 64) {
             const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
-            float2 *dst = lds + slot(4 * v);
+            float2 *dst = lds + slot<R>(4 * v);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = fetch_sample(p, src, nullptr, n + i);
         }
@@ -273,12 +278,12 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
             __builtin_shufflevector(td, td, 0, 1), __builtin_shufflevector(td, td, 2, 3),
             __builtin_shufflevector(td, td, 4, 5), __builtin_shufflevector(td, td, 6, 7)};
 
-        // output r of this lane sits at window slot-index Tp + 16*tid + r; tap
-        // kc+kk reads Tp + 16*tid + r - kc - kk = 16*tid + 32*m + (w + 32),
-        // w = r - kk, m = (Tp - kc - 32)/32.
+        // output r of this lane sits at window index Tp + R*tid + r; tap kc+kk reads
+        // Tp + R*tid + r - kc - kk = R*tid + 32*m + (w + 32),  w = r - kk, m = (Tp - kc - 32)/32;
+        // R*tid and 32*m are multiples of R, so their pad slots add up separately
         const uint32_t m = nchunks - 1 - c;
-        const v2f *base = reinterpret_cast<const v2f *>(lds + 17u * tid + 34u * m);
-        fir1_chunk<EXACT>(acc, tpair, base, std::make_integer_sequence<int, kFirR + kTapChunk - 1>{});
+        const v2f *base = reinterpret_cast<const v2f *>(lds + (uint32_t)(R + 1) * tid + (32u + 32u / R) * m);
+        fir1_chunk<EXACT, R>(acc, tpair, base, std::make_integer_sequence<int, R + kTapChunk - 1>{});
     }
 
     // ---- threshold, guard band, pack -----------------------------------------
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
             asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(acc[r]));
             const float pf = sq.x + sq.y;
             if (pf >= p.p_lo && !(pf >= p.p_hi) && o0 + r < p.n_out) {
-                const float2 y = fir1_exact_output(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps);
+                const float2 y = fir1_exact_output<R>(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps);
                 const float pe = power_ref(y.x, y.y);
                 mask = (mask & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
                 redo++;
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
     {
         const uint32_t keep = o0 >= p.n_out ? 0u : (o0 + R <= p.n_out ? (uint32_t)R : (uint32_t)(p.n_out - o0));
         const uint32_t prev_top = __shfl_up(mask >> (R - 1), 1);       // bit 15 of the lane before
-        uint32_t ch = (mask ^ (mask << 1)) & 0xfffeu;
+        uint32_t ch = (mask ^ (mask << 1)) & ((1u << R) - 2u);
         if (tid != 0) ch |= (mask ^ prev_top) & 1u;
         ch &= keep >= 32 ? 0xffffffffu : ((1u << keep) - 1u);
         uint32_t cnt = __popc(ch);
@@ -348,13 +353,18 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> (R - 1)) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = cnt | (first << 30) | (last << 31);
     }
 
-    // four lanes x 16 bits -> one 64-bit word
-    const uint32_t pair = mask | (__shfl_xor(mask, 1) << 16);      // valid on even lanes
-    const uint32_t hi = __shfl_xor(pair, 2);                       // lane+2's pair
-    if ((tid & 3u) == 0) words[(t0 >> 6) + (tid >> 2)] = (uint64_t)pair | ((uint64_t)hi << 32);
+    // 64 / R lanes x R bits -> one 64-bit word
+    constexpr uint32_t kLanesPerWord = 64u / R;
+    uint64_t w64 = (uint64_t)mask << (R * (tid % kLanesPerWord));
+#pragma unroll
+    for (uint32_t d = 1; d < kLanesPerWord; d <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)w64, (int)d), hi = __shfl_xor((uint32_t)(w64 >> 32), (int)d);
+        w64 |= (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    if (tid % kLanesPerWord == 0) words[(t0 >> 6) + tid / kLanesPerWord] = w64;
 }
 
 // ---------------------------------------------------------------------------
@@ -851,8 +861,11 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64
 // launchers
 // ---------------------------------------------------------------------------
 
+static int fir1_R(uint32_t Tp) { return Tp <= kFir1ShortTaps ? kFir1RShort : kFir1RLong; }
+
 static size_t fir1_lds_bytes(uint32_t Tp) {
-    return (size_t)kFirWgWaves * fir1_wave_slots(Tp) * sizeof(float2);
+    const uint32_t slots = fir1_R(Tp) == kFir1RShort ? fir1_wave_slots<kFir1RShort>(Tp) : fir1_wave_slots<kFir1RLong>(Tp);
+    return (size_t)kFirWgWaves * slots * sizeof(float2);
 }
 
 static void gen_level_sizes(const FrontParams &p, uint32_t len[kMaxStages + 1]) {
@@ -933,7 +946,8 @@ static bool use_fir2(const FrontParams &p) {
 }
 
 uint64_t front_wave_tiles(const FrontParams &p) {
-    if (p.num_stages == 0 || use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * kFirWaves;
+    if (p.num_stages == 0) return ((p.n_out + kFirTile - 1) / kFirTile) * (kFirTile / kWaveTile);
+    if (use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * (kFirTile / (64 * fir1_R(p.stage[0].ntaps_pad)));
     if (use_fir2(p)) {
         const uint64_t per_wg = (uint64_t)kFir2Waves * Fir2Dec4::F;
         return ((p.n_out + per_wg - 1) / per_wg) * kFir2Waves;
@@ -942,7 +956,8 @@ uint64_t front_wave_tiles(const FrontParams &p) {
 }
 
 uint32_t front_tile_bits(const FrontParams &p) {
-    if (p.num_stages == 0 || use_fir1(p)) return kWaveTile;
+    if (p.num_stages == 0) return kWaveTile;
+    if (use_fir1(p)) return 64 * fir1_R(p.stage[0].ntaps_pad);
     if (use_fir2(p)) return Fir2Dec4::F;
     return 0;
 }
@@ -959,18 +974,23 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         const size_t lds = fir1_lds_bytes(p.stage[0].ntaps_pad);
         {
             // whole 4096-output blocks, so every bit word of the capture is written
-            const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * (kFirWaves / kFirWgWaves);
+            const int R = fir1_R(p.stage[0].ntaps_pad);
+            const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * (kFirTile / (64 * R) / kFirWgWaves);
             dim3 grid((uint32_t)tiles, num_captures);
-            hipError_t e;
-            if (exact) {
-                e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir1_bits_kernel<true>), lds);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(fir1_bits_kernel<true>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
+            const void *fn;
+            if (R == kFir1RShort) {
+                fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RShort>)
+                           : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RShort>);
             } else {
-                e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fir1_bits_kernel<false>), lds);
-                if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(fir1_bits_kernel<false>, grid, dim3(64 * kFirWgWaves), lds, stream, p);
+                fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RLong>)
+                           : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RLong>);
             }
+            hipError_t e = ensure_dynamic_lds(fn, lds);
+            if (e != hipSuccess) return e;
+            FrontParams pp = p;
+            void *args[] = {&pp};
+            e = hipLaunchKernel(fn, grid, dim3(64 * kFirWgWaves), args, lds, stream);
+            if (e != hipSuccess) return e;
             return hipGetLastError();
         }
     }

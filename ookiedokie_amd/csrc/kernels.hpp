@@ -18,6 +18,10 @@ constexpr int kFirR = 16;               // outputs per lane in the 1-stage kerne
 constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
 constexpr int kFirWaves = kFirThreads / 64;     // 1024-output wave tiles per 4096-output block
 constexpr int kFirWgWaves = 1;                  // wave tiles per workgroup of the 1-stage kernel
+// outputs per lane of the 1-stage kernel (tile = 64 * R): short filters use small tiles (finer
+// quiet shortcut: -6 % on the bench capture), long ones the MAC-efficient large tile
+constexpr int kFir1RShort = 8, kFir1RLong = 16;
+constexpr uint32_t kFir1ShortTaps = 64;         // padded tap count up to which the small tile is used
 constexpr int kWaveTile = 64 * kFirR;           // 1024 outputs per wavefront
 constexpr int kQuietCounters = 1024;
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
