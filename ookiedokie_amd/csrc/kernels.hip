@@ -861,10 +861,14 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64
 // launchers
 // ---------------------------------------------------------------------------
 
-static int fir1_R(uint32_t Tp) { return Tp <= kFir1ShortTaps ? kFir1RShort : kFir1RLong; }
+// small tiles only pay through the quiet shortcut: none without it (quiet_lsb 0)
+static int fir1_R(const FrontParams &p) {
+    return (p.stage[0].ntaps_pad <= kFir1ShortTaps && p.quiet_lsb > 0) ? kFir1RShort : kFir1RLong;
+}
 
-static size_t fir1_lds_bytes(uint32_t Tp) {
-    const uint32_t slots = fir1_R(Tp) == kFir1RShort ? fir1_wave_slots<kFir1RShort>(Tp) : fir1_wave_slots<kFir1RLong>(Tp);
+static size_t fir1_lds_bytes(const FrontParams &p) {
+    const uint32_t Tp = p.stage[0].ntaps_pad;
+    const uint32_t slots = fir1_R(p) == kFir1RShort ? fir1_wave_slots<kFir1RShort>(Tp) : fir1_wave_slots<kFir1RLong>(Tp);
     return (size_t)kFirWgWaves * slots * sizeof(float2);
 }
 
@@ -936,7 +940,7 @@ hipError_t ensure_dynamic_lds(const void *func, size_t bytes) {
 
 static bool use_fir1(const FrontParams &p) {
     return p.num_stages == 1 && p.stage[0].decim == 1 && p.origin == 0 && !p.iq_f32 &&
-           fir1_lds_bytes(p.stage[0].ntaps_pad) <= 160 * 1024;
+           fir1_lds_bytes(p) <= 160 * 1024;
 }
 
 static bool use_fir2(const FrontParams &p) {
@@ -947,7 +951,7 @@ static bool use_fir2(const FrontParams &p) {
 
 uint64_t front_wave_tiles(const FrontParams &p) {
     if (p.num_stages == 0) return ((p.n_out + kFirTile - 1) / kFirTile) * (kFirTile / kWaveTile);
-    if (use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * (kFirTile / (64 * fir1_R(p.stage[0].ntaps_pad)));
+    if (use_fir1(p)) return ((p.n_out + kFirTile - 1) / kFirTile) * (kFirTile / (64 * fir1_R(p)));
     if (use_fir2(p)) {
         const uint64_t per_wg = (uint64_t)kFir2Waves * Fir2Dec4::F;
         return ((p.n_out + per_wg - 1) / per_wg) * kFir2Waves;
@@ -957,7 +961,7 @@ uint64_t front_wave_tiles(const FrontParams &p) {
 
 uint32_t front_tile_bits(const FrontParams &p) {
     if (p.num_stages == 0) return kWaveTile;
-    if (use_fir1(p)) return 64 * fir1_R(p.stage[0].ntaps_pad);
+    if (use_fir1(p)) return 64 * fir1_R(p);
     if (use_fir2(p)) return Fir2Dec4::F;
     return 0;
 }
@@ -971,10 +975,10 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         return hipGetLastError();
     }
     if (use_fir1(p)) {
-        const size_t lds = fir1_lds_bytes(p.stage[0].ntaps_pad);
+        const size_t lds = fir1_lds_bytes(p);
         {
             // whole 4096-output blocks, so every bit word of the capture is written
-            const int R = fir1_R(p.stage[0].ntaps_pad);
+            const int R = fir1_R(p);
             const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * (kFirTile / (64 * R) / kFirWgWaves);
             dim3 grid((uint32_t)tiles, num_captures);
             const void *fn;
