@@ -92,11 +92,18 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
             const uint32_t t0 = blk * tpb;
             uint32_t prev_last = t0 ? ti[t0 - 1] >> 31 : 0u;
             uint32_t c = 0;
-            for (uint32_t t = 0; t < tpb; ++t) {
-                if ((uint64_t)(t0 + t) * tile_bits >= p.n_out) break;      // tile holds no sample
-                const uint32_t info = ti[t0 + t];
-                c += (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last);
-                prev_last = info >> 31;
+            // a block's tiles are 4, 8 or 16 consecutive words: fetch them 16 B at a time
+            for (uint32_t t4 = 0; t4 < tpb; t4 += 4) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(ti + t0 + t4);
+                const uint32_t info4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    // a tile that holds no sample was not written by the front end
+                    const bool live = (uint64_t)(t0 + t4 + j) * tile_bits < p.n_out;
+                    const uint32_t info = live ? info4[j] : 0u;
+                    c += live ? (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+                    prev_last = live ? info >> 31 : prev_last;
+                }
             }
             v[i] = c;
             p.blk_count[b] = c;         // edge_write skips empty blocks by it
