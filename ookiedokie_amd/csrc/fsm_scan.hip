@@ -496,7 +496,6 @@ __device__ __forceinline__ uint32_t parity_order(uint32_t p, uint32_t count) {
 // then the two skip states).  Lanes of a wave share the start state and take
 // leaves of equal level (even leaves first, then odd), so they follow nearly
 // the same path.
-__shared__ uint32_t s_nuniq;
 
 // packed result of a class simulation
 constexpr uint32_t kPkAbsolute = 0x80000000u;   // [15:0] end code, [23:16] its state (S for skip / poison)
@@ -980,7 +979,6 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
     __shared__ uint16_t s_skip[256][2];
-    if (threadIdx.x == 0) s_nuniq = 0;
     load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
     __syncthreads();
     if (*sp.fallback) return;
