@@ -471,6 +471,7 @@ struct ScanParams {
     uint16_t *group_tab;        // [groups][Dp]
     uint16_t *group_in;         // [groups]
     uint16_t *cap_end;          // [captures] state after the last regular leaf
+    uint16_t *cap_first;        // [captures] state after the first span (leaf kernel -> walk kernel)
 };
 
 namespace {
@@ -985,7 +986,22 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     const uint32_t D = T.D, LB = sp.leaf_block;
     const BlockLds b = carve(LB, D);
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
-    for (uint32_t gb = blockIdx.x; gb < total; gb += gridDim.x) {
+    for (uint32_t gb = blockIdx.x; gb < total + sp.f.num_captures; gb += gridDim.x) {
+        if (gb >= total) {
+            // one extra item per capture: its first span (samples 0 .. first edge) from the
+            // concrete incoming state, for the walk kernel (a cold simulation there would sit
+            // on the critical path; here it runs beside the blocks)
+            if (threadIdx.x == 0) {
+                const uint32_t cap = gb - total;
+                uint64_t e0;
+                const uint64_t ne = cap_edges(sp.f, cap, e0);
+                PSim f;
+                Acc a;
+                const bool alive = first_leaf(T, sp, sp.f.edges + e0, ne, f, a);
+                sp.cap_first[cap] = (uint16_t)encode_post(T, f, a, alive);
+            }
+            continue;
+        }
         uint32_t cap, lb;
         locate_block(sp, gb, cap, lb);
         uint64_t e0;
@@ -1075,24 +1091,13 @@ __global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) {
-    __shared__ LTab T;
     __shared__ uint32_t x;
-    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
-    __syncthreads();
     if (*sp.fallback) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 group tables at a time
     const uint32_t max_stage = 128;
     for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
-        uint64_t e0;
-        const uint64_t ne = cap_edges(sp.f, cap, e0);
-        const uint64_t *edges = sp.f.edges + e0;
         const uint32_t g0 = sp.cap_group_off[cap], g1 = sp.cap_group_off[cap + 1];
-        if (threadIdx.x == 0) {
-            PSim f;
-            Acc a;
-            const bool alive = first_leaf(T, sp, edges, ne, f, a);
-            x = encode_post(T, f, a, alive);
-        }
+        if (threadIdx.x == 0) x = sp.cap_first[cap];        // from the leaf kernel
         __syncthreads();
         for (uint32_t gs = g0; gs < g1; gs += max_stage) {
             const uint32_t ng = min(max_stage, g1 - gs);
@@ -1808,6 +1813,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.group_tab = a.group_tab;
     sp.group_in = a.group_in;
     sp.cap_end = a.cap_end;
+    sp.cap_first = a.cap_first;
     const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S);
     const size_t lds_group = (size_t)kGroup * sp.Dp * 2;
     const size_t lds_walk = (size_t)128 * sp.Dp * 2;

@@ -239,6 +239,7 @@ struct FsmScanArgs {
     uint16_t *group_tab;        // [total_blocks_cap / 16 + captures + 1][D rounded up to 8]
     uint16_t *group_in;         // same count
     uint16_t *cap_end;          // [captures]
+    uint16_t *cap_first;        // [captures]
 };
 
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);

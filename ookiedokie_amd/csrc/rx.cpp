@@ -595,6 +595,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.group_tab = d_group_tab.p;
     a.group_in = d_group_in.p;
     a.cap_end = d_cap_end.p;
+    a.cap_first = d_cap_end.p + (max_captures + 8);
     a.block_in = d_block_in.p;
     a.cap_block_off = d_cap_block_off.p;
     a.total_blocks_cap = scan_blocks_cap;
@@ -981,7 +982,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 rc |= rx->d_cap_group_off.alloc(caps + 1);
                 rc |= rx->d_group_tab.alloc(ngroups * ((rx->scan_D + 7u) & ~7u) + 64);
                 rc |= rx->d_group_in.alloc(ngroups);
-                rc |= rx->d_cap_end.alloc(caps + 8);
+                rc |= rx->d_cap_end.alloc(2 * (caps + 8));         // + cap_first
             }
             rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
             rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
