@@ -457,7 +457,7 @@ struct ScanParams {
     uint32_t total_blocks_cap;
     uint32_t leaf_block;        // leaves per block (<= 256)
     uint32_t *fin_off;          // [captures + 1] prefix of finish-block counts
-    unsigned long long *fagg;   // [finish blocks][4] appends, outputs, errors, last epoch start + 1, each | stamp << 32
+    unsigned long long *fagg;   // [finish blocks][4, two used] appends | outputs << 20, errors | (last epoch start + 1) << 12; each | stamp << 32
     uint32_t *fin_ticket;       // next finish block to hand out (zero at launch)
     uint32_t run_stamp;         // != 0, different from the previous launch's
     uint32_t fin_blocks_cap;
@@ -1427,11 +1427,11 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
         FinLeaf L;
         fin_block_scan(sp, cap, fb, L, sh);
         if (tid == 0) {
+            // two stamped words: appends (20 bits) | outputs << 20 (12), errors (12) | epoch << 12 (20)
+            // -- 1024 leaves of at most 255 appends, 2 outputs, 1 error each
             unsigned long long *slot = sp.fagg + 4 * (size_t)g;
-            agg_store(slot + 0, L.a_tot, stamp);
-            agg_store(slot + 1, L.o_tot, stamp);
-            agg_store(slot + 2, L.e_tot, stamp);
-            agg_store(slot + 3, L.r_tot, stamp);
+            agg_store(slot + 0, L.a_tot | (L.o_tot << 20), stamp);
+            agg_store(slot + 1, L.e_tot | (L.r_tot << 12), stamp);
         }
         // ---- predecessors -----------------------------------------------------------------
         const uint32_t g0 = sp.fin_off[cap];
@@ -1439,11 +1439,12 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             uint32_t a = 0, o = 0, e = 0, last = 0;
             for (uint32_t j = tid; j < g; j += blockDim.x) {
                 const unsigned long long *slot = sp.fagg + 4 * (size_t)j;
-                o += agg_load(slot + 1, stamp);
-                e += agg_load(slot + 2, stamp);
+                const uint32_t w0 = agg_load(slot + 0, stamp), w1 = agg_load(slot + 1, stamp);
+                o += w0 >> 20;
+                e += w1 & 0xfffu;
                 if (j >= g0) {
-                    a += agg_load(slot + 0, stamp);
-                    if (agg_load(slot + 3, stamp)) last = j + 1;
+                    a += w0 & 0xfffffu;
+                    if (w1 >> 12) last = j + 1;
                 }
             }
             if (a) atomicAdd(&s_acc[0], a);
@@ -1462,10 +1463,10 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             if (tid == 0) s_acc[0] = 0;
             __syncthreads();
             uint32_t a = 0;
-            for (uint32_t j = g0 + tid; j + 1 < jr; j += blockDim.x) a += agg_load(sp.fagg + 4 * (size_t)j, stamp);
+            for (uint32_t j = g0 + tid; j + 1 < jr; j += blockDim.x) a += agg_load(sp.fagg + 4 * (size_t)j, stamp) & 0xfffffu;
             if (a) atomicAdd(&s_acc[0], a);
             __syncthreads();
-            epoch_in = nb0 + s_acc[0] + agg_load(sp.fagg + 4 * (size_t)(jr - 1) + 3, stamp) - 1;
+            epoch_in = nb0 + s_acc[0] + (agg_load(sp.fagg + 4 * (size_t)(jr - 1) + 1, stamp) >> 12) - 1;
             __syncthreads();
         }
         uint64_t e0;
