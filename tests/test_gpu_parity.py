@@ -678,3 +678,54 @@ def test_full_size_properties_1GiB(ok):
     e = rx.edges()
     assert (np.diff(e.astype(np.int64)) > 0).all()
     assert got.stats["num_edges"] == e.size
+
+
+# ------------------------------------------------------------------ hygiene ----
+
+def test_contexts_release_their_memory(ok, vectors):
+    """Create / run / destroy in a loop: device memory must come back (buffers,
+    pinned staging, streams, events of rx contexts, formatters, backends)."""
+    import torch
+    g, iq = _g1(vectors)
+    iq = iq[:2 * 300000]
+    f = _flt(ok, "fs128_fs16_dec4")
+    d = _dev(ok, "p3l-nexa2012", RATE // 4)
+
+    def once():
+        rx = ok.Receiver(f, d, max_samples=iq.size // 2, keep_fir=True)
+        rx.rx(iq)                               # host path: pinned ingest buffers too
+        rx.fir_sc16q11()
+        rx.dig_text()
+        fm = ok.Formatter(d)
+        fm.print_messages(rx.result(), 8192, 4)
+        fm.close()
+        rx.close()
+
+    once()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        once()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 12 create/destroy cycles" % (free0 - free1)
+
+
+def test_context_is_reusable_across_sizes(ok, oracle, vectors):
+    """One context, captures of different lengths back to back (state of the
+    previous run must not leak into the next: header counters, tile info,
+    stamped aggregates, edge lists)."""
+    g, iq = _g1(vectors, noise_seed=31)
+    f = _flt(ok, "fs32_fs4")
+    of = _ofir(oracle, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    rx = ok.Receiver(f, d, max_samples=iq.size // 2)
+    for n in (iq.size // 2, 5000, 0, 450000, 1, iq.size // 2, 820000):
+        part = iq[:2 * n]
+        got = rx.rx(part)
+        want = oracle.rx(part, of, 0.1, od, 8192, want_bits=True)
+        assert list(got.msg_samples) == list(want.msg_samples), n
+        assert (got.payloads == want.payloads).all()
+        assert list(rx.edges()) == list(edges_of(want.bits)), n
+    rx.close()
