@@ -241,6 +241,18 @@ int ookd_rx_process_device(ookd_rx *rx, const void *d_iq,
                            uint64_t samples_per_capture,
                            uint64_t capture_stride_samples);
 
+/* The same split in two, for hosts that overlap captures: submit queues the
+ * whole run on the context's stream and returns; wait blocks until its
+ * results are in host memory.  One run in flight per context -- use two
+ * contexts (each has its own stream) to let the memory-bound front end of
+ * one capture overlap the latency-bound state machine of the previous one.
+ * ookd_rx_process_device == submit + wait. */
+int ookd_rx_submit_device(ookd_rx *rx, const void *d_iq,
+                          uint32_t num_captures,
+                          uint64_t samples_per_capture,
+                          uint64_t capture_stride_samples);
+int ookd_rx_wait(ookd_rx *rx);
+
 /* Same over a host buffer: stages it to HBM first (PCIe-bound; never the
  * figure bench.py reports). */
 int ookd_rx_process_host(ookd_rx *rx, const int16_t *iq,

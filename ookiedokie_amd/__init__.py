@@ -159,6 +159,8 @@ _PROTOTYPES = {
     "ookd_rx_create": (C.c_void_p, [C.POINTER(RxConfig), C.c_void_p, C.c_void_p]),
     "ookd_rx_destroy": (None, [C.c_void_p]),
     "ookd_rx_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ookd_rx_submit_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ookd_rx_wait": (C.c_int, [C.c_void_p]),
     "ookd_rx_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "ookd_rx_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                       C.c_int, C.POINTER(FsmState), C.POINTER(FsmState)]),
@@ -544,6 +546,16 @@ class Receiver:
         turn them into Python objects when (and if) the caller wants them."""
         _check(lib().ookd_rx_process_device(self._h, d_iq_ptr, num_captures, samples_per_capture,
                                             stride if stride is not None else samples_per_capture))
+
+    def submit_device(self, d_iq_ptr: int, samples_per_capture: int, num_captures: int = 1,
+                      stride: Optional[int] = None) -> None:
+        """Queue a run on this context's stream and return (ookd_rx_submit_device)."""
+        _check(lib().ookd_rx_submit_device(self._h, d_iq_ptr, num_captures, samples_per_capture,
+                                           stride if stride is not None else samples_per_capture))
+
+    def wait(self) -> None:
+        """Block until the submitted run's results are in host memory (ookd_rx_wait)."""
+        _check(lib().ookd_rx_wait(self._h))
 
     def result(self) -> RxResult:
         return self._result()

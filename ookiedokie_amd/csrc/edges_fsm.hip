@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
 // (coalesced 16 B per lane), writes group-local exclusive prefixes and the
 // group total.
 __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t wave_sum[4];
     const uint32_t n = p.num_captures * p.blocks_per_cap;
     const uint32_t tid = threadIdx.x;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
 // level 2: one workgroup scans the group totals in place (exclusive) and
 // publishes the grand total in blk_offset[n].
 __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams p) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t wtot[16];
     const uint32_t n = p.num_captures * p.blocks_per_cap;
     const uint32_t ng = (n + kScanGroup - 1) / kScanGroup;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
 constexpr uint32_t kWriteSpan = 4;
 
 __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = lane_id();
     const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(1024) void fsm_gather_kernel(const FsmParams p) {
 // and the first messages are written through the host-mapped pointers, then
 // the device header is zeroed for the next run.
 __global__ __launch_bounds__(256) void publish_kernel(PublishParams p) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint64_t s_total;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) s_total = p.d_hdr[p.totals_word] | ((uint64_t)p.d_hdr[p.totals_word + 1] << 32);

@@ -936,6 +936,7 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint
 // prefix of per-capture block counts: scan blocks (regular leaves) and finish
 // blocks (all leaves); one workgroup
 __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t wtot[kScanThreads / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t nc = sp.f.num_captures;
@@ -976,6 +977,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
 }
 
 __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
@@ -1071,6 +1073,7 @@ __device__ __forceinline__ void stage_group(const ScanParams &sp, uint32_t b0, u
 }
 
 __global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     if (*sp.fallback) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kGroup][Dp]
     const uint32_t D = sp.f.tables->num_states * (sp.f.tables->max_bits + 2) + 3;
@@ -1091,6 +1094,7 @@ __global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t x;
     if (*sp.fallback) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 group tables at a time
@@ -1123,6 +1127,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
 }
 
 __global__ __launch_bounds__(256) void scan_blockin_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     if (*sp.fallback) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);
     const uint32_t total = sp.cap_group_off[sp.f.num_captures];
@@ -1145,6 +1150,7 @@ __global__ __launch_bounds__(256) void scan_blockin_kernel(ScanParams sp) {
 
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
 __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
@@ -1404,6 +1410,7 @@ __device__ __forceinline__ uint64_t pool_start(uint64_t e0, uint32_t cap) {
 
 // append values by ordinal, error list, message descriptors (sample, epoch, count)
 __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t sh[4][kFinBlock];
     __shared__ uint32_t s_g;
     __shared__ uint32_t s_acc[4];       // appends (same capture), outputs, errors (all), last block with a reset + 1
@@ -1535,6 +1542,7 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
 
 // gathers payload bits: one lane per message, then one per capture for the outgoing state
 __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     if (*sp.fallback) return;
     const uint32_t max_bits = sp.f.tables->max_bits;
     const uint32_t nbytes = (max_bits + 7u) >> 3;

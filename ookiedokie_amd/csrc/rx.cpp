@@ -2,6 +2,7 @@
 // demodulation entry (replaces the body of the reference loop,
 // src/ookiedokie.c:243-288, for whole captures resident in HBM).
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cinttypes>
@@ -10,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "common.hpp"
 #include "ingest.hpp"
@@ -44,6 +46,23 @@ struct ResultHeader {
     uint32_t fin_ticket;        // work counter of the scan's finish kernel
     uint32_t pad;
 };
+
+// Front-end kernels of different contexts on one device take turns: they are
+// HBM bound, so running two at once only makes both slower, while everything
+// after them (edges, state machine: latency bound) overlaps the next
+// context's front end.  One event per device, re-recorded after every front
+// kernel; a context waits for the latest record before launching its own.
+constexpr int kMaxGateDevices = 64;
+std::atomic<int> g_live_contexts[kMaxGateDevices];
+
+hipEvent_t front_gate(int dev) {
+    static std::mutex m;
+    static hipEvent_t ev[kMaxGateDevices] = {};
+    if (dev < 0 || dev >= kMaxGateDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    return ev[dev];
+}
 
 template <typename T>
 struct DevBuf {
@@ -310,7 +329,9 @@ struct ookd_rx {
     uint32_t final_parity = 0;
     ookd_rx_stats stats{};
 
+    bool counted = false;           // this context is in g_live_contexts
     ~ookd_rx() {
+        if (counted && dev >= 0 && dev < kMaxGateDevices) g_live_contexts[dev].fetch_sub(1);
         (void)hipSetDevice(dev);
         d_taps.release();
         d_tables.release();
@@ -456,6 +477,9 @@ struct ookd_rx {
     int fsm_scan(const FsmStateDev *first);
     int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
     int fetch_results();
+    int enqueue_publish();
+    int collect_results();
+    bool submitted = false;         // a run is queued (ookd_rx_submit_device) and not yet waited for
 };
 
 int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
@@ -466,9 +490,13 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
+    hipEvent_t gate = nullptr;
+    if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) gate = front_gate(dev);
+    if (gate) HIPCHK(hipStreamWaitEvent(stream, gate, 0));
     HIPCHK(hipEventRecord(ev[0], stream));
     HIPCHK(launch_front(fp, run_caps, exact, stream));
     HIPCHK(hipEventRecord(ev[1], stream));
+    if (gate) HIPCHK(hipEventRecord(gate, stream));
     if (run_n_out > 0) HIPCHK(launch_edges(edge_params(), stream));
     return OOKD_OK;
 }
@@ -654,6 +682,13 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
 }
 
 int ookd_rx::fetch_results() {
+    int rc = enqueue_publish();
+    if (rc != OOKD_OK) return rc;
+    return collect_results();
+}
+
+// Last kernel of a run: header and first messages into pinned host memory.
+int ookd_rx::enqueue_publish() {
     const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
     {
         static_assert(sizeof(ResultHeader) % 4 == 0 && sizeof(ResultHeader) / 4 <= 256, "header is published by one workgroup");
@@ -671,6 +706,12 @@ int ookd_rx::fetch_results() {
         pp.first_msgs = first;
         HIPCHK(launch_publish(pp, stream));
     }
+    return OOKD_OK;
+}
+
+// Waits for the run queued on the stream and turns it into host-side results.
+int ookd_rx::collect_results() {
+    const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
     uint32_t total_edges = 0;
     HIPCHK(hipStreamSynchronize(stream));
     hdr_dirty = false;              // the publish kernel left the device header zeroed
@@ -1010,16 +1051,24 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         set_error("pinned result buffers are not mapped into the device");
         return nullptr;
     }
+    if (rx->dev >= 0 && rx->dev < kMaxGateDevices) {
+        g_live_contexts[rx->dev].fetch_add(1);
+        rx->counted = true;
+    }
     return rx.release();
 }
 
 void ookd_rx_destroy(ookd_rx *rx) { delete rx; }
 
-int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
-                           uint64_t samples_per_capture, uint64_t capture_stride_samples) {
+int ookd_rx_submit_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
+                          uint64_t samples_per_capture, uint64_t capture_stride_samples) {
     clear_error();
     if (!rx || (!d_iq && samples_per_capture)) {
-        set_error("ookd_rx_process_device: null argument");
+        set_error("ookd_rx_submit_device: null argument");
+        return OOKD_ERR_ARG;
+    }
+    if (rx->submitted) {
+        set_error("ookd_rx_submit_device: the previous run has not been waited for");
         return OOKD_ERR_ARG;
     }
     if (num_captures == 0 || num_captures > rx->max_captures || samples_per_capture > rx->max_samples) {
@@ -1038,23 +1087,42 @@ int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
     rx->geometry(samples_per_capture, true, rx->run_n_in, rx->run_n_out, rx->run_words,
                  rx->run_blocks, rx->run_segs_per_cap);
     rx->stats = ookd_rx_stats{};
+    int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
+    if (rc != OOKD_OK) return rc;
+    rc = rx->run_state_machine(nullptr, true);
+    if (rc != OOKD_OK) return rc;
+    rc = rx->enqueue_publish();
+    if (rc != OOKD_OK) return rc;
+    rx->submitted = true;
+    return OOKD_OK;
+}
+
+int ookd_rx_wait(ookd_rx *rx) {
+    clear_error();
+    if (!rx || !rx->submitted) {
+        set_error("ookd_rx_wait: nothing was submitted");
+        return OOKD_ERR_ARG;
+    }
+    rx->submitted = false;
+    HIPCHK(hipSetDevice(rx->dev));
+    return rx->collect_results();
+}
+
+int ookd_rx_process_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
+                           uint64_t samples_per_capture, uint64_t capture_stride_samples) {
     static const bool timing = getenv("OOKD_DEBUG_TIME") != nullptr;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
-    int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
+    int rc = ookd_rx_submit_device(rx, d_iq, num_captures, samples_per_capture, capture_stride_samples);
     if (rc != OOKD_OK) return rc;
     const auto t1 = clk::now();
-    rc = rx->run_state_machine(nullptr, true);
-    if (rc != OOKD_OK) return rc;
-    const auto t2 = clk::now();
-    rc = rx->fetch_results();
+    rc = ookd_rx_wait(rx);
     if (timing) {
-        const auto t3 = clk::now();
+        const auto t2 = clk::now();
         auto us = [](clk::time_point a, clk::time_point b) {
             return std::chrono::duration<double, std::micro>(b - a).count();
         };
-        fprintf(stderr, "[ookd] host us: enqueue front+edges %.1f, enqueue fsm %.1f, fetch (wait+copy) %.1f\n",
-                us(t0, t1), us(t1, t2), us(t2, t3));
+        fprintf(stderr, "[ookd] host us: enqueue %.1f, wait + collect %.1f\n", us(t0, t1), us(t1, t2));
     }
     return rc;
 }

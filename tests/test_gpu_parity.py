@@ -729,3 +729,31 @@ def test_context_is_reusable_across_sizes(ok, oracle, vectors):
         assert (got.payloads == want.payloads).all()
         assert list(rx.edges()) == list(edges_of(want.bits)), n
     rx.close()
+
+
+def test_submit_wait_two_contexts(ok, oracle, vectors):
+    """ookd_rx_submit_device / ookd_rx_wait with two contexts in flight give the
+    results of the blocking call, whatever the interleaving."""
+    import torch
+    g, iq = _g1(vectors, noise_seed=41)
+    f = _flt(ok, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012")
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, _odev(oracle, "p3l-nexa2012"), 8192)
+    n = iq.size // 2
+    t = torch.from_numpy(iq.copy()).cuda()
+    a = ok.Receiver(f, d, max_samples=n)
+    b = ok.Receiver(f, d, max_samples=n)
+    with pytest.raises(ok.OokdError):
+        a.wait()                            # nothing submitted
+    for _ in range(3):
+        a.submit_device(t.data_ptr(), n)
+        b.submit_device(t.data_ptr(), n)
+        with pytest.raises(ok.OokdError):
+            a.submit_device(t.data_ptr(), n)    # one run in flight per context
+        b.wait()
+        a.wait()
+        for r in (a.result(), b.result()):
+            assert list(r.msg_samples) == list(want.msg_samples)
+            assert (r.payloads == want.payloads).all()
+    a.close()
+    b.close()
