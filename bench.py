@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--exact", action="store_true", help="unfused reference-order FIR everywhere")
     ap.add_argument("--filter", default="fs32_fs4", help=argparse.SUPPRESS)   # experiments only
     ap.add_argument("--contexts", type=int, default=2,
-                    help="rx contexts (= HIP streams) with a capture in flight: 2 lets the memory-bound front "
+                    help="rx contexts (= HIP streams) with a capture in flight: 2 or 3 let the memory-bound front "
                          "end of one step overlap the latency-bound state machine of the step before; 1 = "
                          "strictly one step after the other")
     ap.add_argument("--no-quiet-skip", action="store_true",
