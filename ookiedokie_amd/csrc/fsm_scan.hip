@@ -34,6 +34,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -67,27 +68,13 @@ struct LTab {
 
 __host__ __device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kNone : (uint32_t)v; }
 
-__device__ void load_ltab(LTab &T, const FsmTablesDev *g, uint32_t spb, uint32_t decim) {
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxTriggers; i += blockDim.x) {
-        T.tr[i] = make_uint4(clamp32(g->trig_kmin[i]), clamp32(g->trig_kmax[i]), g->trig_info[i], 0u);
-    }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxStates; i += blockDim.x) {
-        uint32_t msgc = 0;
-        for (uint32_t t = g->state_tbeg[i]; t < g->state_tend[i] && t < (uint32_t)kMaxTriggers; ++t) {
-            if ((g->trig_info[t] & 0xffu) == kCondMsgComplete) msgc = 1;
-        }
-        const uint32_t row = (g->state_tbeg[i] & 0xffu) | ((g->state_tend[i] & 0xffu) << 8) |
-                             ((g->state_flags[i] & 1u) << 16) | (msgc << 17);
-        T.st[i] = make_uint4(clamp32(g->state_kmin[i]), clamp32(g->state_kmax[i]), clamp32(g->state_kto[i]), row);
-    }
-    if (threadIdx.x == 0) {
-        T.max_bits = g->max_bits;
-        T.S = g->num_states;
-        T.NB1 = g->max_bits + 2;
-        T.D = g->num_states * (g->max_bits + 2) + 3;
-        T.spb = spb;
-        T.decim = decim;
-    }
+// The tables are laid out once on the host (fsm_scan_fill_ltab): the kernels
+// fetch the image with 16-byte loads.
+static_assert(sizeof(LTab) % 16 == 0, "LTab is copied in 16-byte pieces");
+__device__ __forceinline__ void copy_ltab(LTab &T, const void *g) {
+    const uint4 *src = static_cast<const uint4 *>(g);
+    uint4 *dst = reinterpret_cast<uint4 *>(&T);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(LTab) / 16); i += blockDim.x) dst[i] = src[i];
 }
 
 // per-lane concrete machine + what happened in the span
@@ -466,6 +453,7 @@ struct ScanParams {
     // span tables (build_leaf_tables): packed result of a span as a function of its
     // length, per (row, level); null = simulate
     const uint32_t *lt_off, *lt_n0, *lt_pk;
+    const void *ltab;           // device copy of the LTab (fsm_scan_fill_ltab)
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -982,7 +970,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
     __shared__ uint16_t s_skip[256][2];
-    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
+    copy_ltab(T, sp.ltab);
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
@@ -1155,7 +1143,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
     __shared__ uint16_t cin[32];
-    load_ltab(T, sp.f.tables, sp.f.spb, sp.f.total_decim);
+    copy_ltab(T, sp.ltab);
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
@@ -1712,6 +1700,13 @@ void row_candidates(const LTab &T, PSim f, uint32_t L, bool first_is_edge, std::
 
 }  // namespace
 
+size_t fsm_scan_ltab_bytes() { return sizeof(LTab); }
+
+void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &g, uint32_t spb, uint32_t decim) {
+    memset(dst, 0, sizeof(LTab));
+    fill_ltab_host(*static_cast<LTab *>(dst), g, spb, decim);
+}
+
 bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
                        std::vector<uint32_t> &n0, std::vector<uint32_t> &pk) {
     std::unique_ptr<LTab> Tp(new LTab());
@@ -1817,6 +1812,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.lt_off = a.lt_off;
     sp.lt_n0 = a.lt_n0;
     sp.lt_pk = a.lt_pk;
+    sp.ltab = a.ltab;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;

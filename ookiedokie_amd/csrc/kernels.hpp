@@ -219,6 +219,7 @@ struct FsmScanArgs {
     uint32_t *leaf_res;         // [edges + captures][2S+2]
     uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
+    const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
     uint16_t *block_in;         // [total_blocks_cap]
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
@@ -243,6 +244,10 @@ struct FsmScanArgs {
 };
 
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);
+// The trigger / state tables in the layout the scan kernels keep in LDS: size, and
+// a host-side fill (16-byte aligned destination) to be uploaded once per context.
+size_t fsm_scan_ltab_bytes();
+void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &tables, uint32_t spb, uint32_t decim);
 // Packed result of a span as a step function of its length, per (row, level)
 // (host side; false = not tabulated, the kernels simulate).
 bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,

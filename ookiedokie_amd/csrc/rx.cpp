@@ -300,6 +300,7 @@ struct ookd_rx {
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab, d_block_in, d_chunk_tab;
     DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
+    DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
@@ -357,6 +358,7 @@ struct ookd_rx {
         d_lt_off.release();
         d_lt_n0.release();
         d_lt_pk.release();
+        d_ltab.release();
         d_leaf_res.release();
         d_cap_group_off.release();
         d_group_tab.release();
@@ -618,6 +620,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_off = d_lt_off.p;
     a.lt_n0 = d_lt_n0.p;
     a.lt_pk = d_lt_pk.p;
+    a.ltab = d_ltab.p;
     a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
@@ -1014,6 +1017,13 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             }
         }
         if (rx->scan_ok) {
+            std::vector<uint4> image((fsm_scan_ltab_bytes() + 15) / 16);
+            fsm_scan_fill_ltab(image.data(), *rx->h_tables, cfg->samples_per_buffer, rx->total_decim);
+            rc |= rx->d_ltab.alloc(image.size());
+            if (rc == OOKD_OK &&
+                hipMemcpy(rx->d_ltab.p, image.data(), image.size() * 16, hipMemcpyHostToDevice) != hipSuccess) {
+                rc = OOKD_ERR_HIP;
+            }
             rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
             rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
