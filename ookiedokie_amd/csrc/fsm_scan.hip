@@ -430,7 +430,6 @@ __host__ __device__ __forceinline__ uint32_t encode_post(const LTab &T, const PS
 struct ScanParams {
     FsmParams f;
     uint16_t *block_tab;
-    uint16_t *block_in;
     uint32_t *cap_block_off;
     LeafEvDev *events;
     uint8_t *app_vals;
@@ -1114,28 +1113,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
     }
 }
 
-__global__ __launch_bounds__(256) void scan_blockin_kernel(ScanParams sp) {
-    __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
-    if (*sp.fallback) return;
-    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);
-    const uint32_t total = sp.cap_group_off[sp.f.num_captures];
-    for (uint32_t gg = blockIdx.x; gg < total; gg += gridDim.x) {
-        uint32_t cap, lg;
-        locate_group(sp, gg, cap, lg);
-        const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
-        const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
-        stage_group(sp, b0, nb, stage);
-        if (threadIdx.x == 0) {
-            uint32_t s = sp.group_in[gg];
-            for (uint32_t j = 0; j < nb; ++j) {
-                sp.block_in[b0 + j] = (uint16_t)s;
-                s = stage[j * sp.Dp + s];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
 __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
@@ -1170,6 +1147,9 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             }
             __syncthreads();
             const uint32_t nch = (count + kChunk - 1) / kChunk;
+            // blocks of this group that precede this one: their tables take the group's
+            // entry state (walk kernel) to this block's
+            const uint32_t jgrp = lb % kGroup;
             {
                 // the leaf kernel's chunk tables of this block
                 const uint16_t *ctab_in = sp.chunk_tab + (size_t)w * (LB / kChunk) * sp.Dp;
@@ -1177,10 +1157,14 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     const uint32_t c = i / D, d = i - c * D;
                     b.ctab[i] = ctab_in[c * sp.Dp + d];
                 }
+                const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)(w - jgrp) * sp.Dp);
+                uint4 *dst = reinterpret_cast<uint4 *>(b.tab);          // the leaf-table area is free here
+                for (uint32_t i = threadIdx.x; i < jgrp * (sp.Dp / 8); i += blockDim.x) dst[i] = src[i];
             }
             __syncthreads();
-            if (threadIdx.x == 0) {             // state entering each chunk
-                uint32_t s = sp.block_in[w];
+            if (threadIdx.x == 0) {             // state entering the block, then each chunk
+                uint32_t s = sp.group_in[sp.cap_group_off[cap] + lb / kGroup];
+                for (uint32_t j = 0; j < jgrp; ++j) s = b.tab[j * sp.Dp + s];
                 for (uint32_t c = 0; c < nch; ++c) {
                     cin[c] = (uint16_t)s;
                     s = b.ctab[c * D + s];
@@ -1789,7 +1773,6 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     ScanParams sp{};
     sp.f = a.f;
     sp.block_tab = a.block_tab;
-    sp.block_in = a.block_in;
     sp.cap_block_off = a.cap_block_off;
     sp.events = a.events;
     sp.app_vals = a.app_vals;
@@ -1836,7 +1819,6 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(scan_leaf_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
     hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
-    hipLaunchKernelGGL(scan_blockin_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);

@@ -220,7 +220,6 @@ struct FsmScanArgs {
     uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
-    uint16_t *block_in;         // [total_blocks_cap]
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]

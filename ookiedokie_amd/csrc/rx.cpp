@@ -298,7 +298,7 @@ struct ookd_rx {
     FsmStateDev pending_first{};
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
-    DevBuf<uint16_t> d_block_tab, d_block_in, d_chunk_tab;
+    DevBuf<uint16_t> d_block_tab, d_chunk_tab;
     DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
     DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
@@ -364,7 +364,6 @@ struct ookd_rx {
         d_group_tab.release();
         d_group_in.release();
         d_cap_end.release();
-        d_block_in.release();
         d_cap_block_off.release();
         d_events.release();
         d_app_vals.release();
@@ -627,7 +626,6 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.group_in = d_group_in.p;
     a.cap_end = d_cap_end.p;
     a.cap_first = d_cap_end.p + (max_captures + 8);
-    a.block_in = d_block_in.p;
     a.cap_block_off = d_cap_block_off.p;
     a.total_blocks_cap = scan_blocks_cap;
     a.events = d_events.p;
@@ -668,13 +666,6 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
         HIPCHK(hipMemcpy(&ne32[1], d_blk_offset.p + run_blocks, 4, hipMemcpyDeviceToHost));
         const uint32_t ne = ne32[1] - ne32[0];
         fprintf(stderr, "[scan] blocks %u..%u ne %u D %u LB %u\n", off[0], off[1], ne, scan_D, scan_leaf_block);
-        std::vector<uint16_t> bin(off[1] ? off[1] : 1), btab((size_t)(off[1] ? off[1] : 1) * scan_D);
-        if (off[1]) {
-            HIPCHK(hipMemcpy(bin.data(), d_block_in.p, off[1] * 2, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(btab.data(), d_block_tab.p, (size_t)off[1] * scan_D * 2, hipMemcpyDeviceToHost));
-            for (uint32_t b = 0; b < off[1] && b < 4; ++b)
-                fprintf(stderr, "[scan] block %u in %u -> out %u\n", b, bin[b], btab[(size_t)b * scan_D + bin[b]]);
-        }
         std::vector<LeafEvDev> evs(ne + 1);
         HIPCHK(hipMemcpy(evs.data(), d_events.p, (ne + 1) * sizeof(LeafEvDev), hipMemcpyDeviceToHost));
         for (uint32_t i = ne > 6 ? ne - 6 : 0; i <= ne; ++i)
@@ -1036,7 +1027,6 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 rc |= rx->d_cap_end.alloc(2 * (caps + 8));         // + cap_first
             }
             rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
-            rc |= rx->d_block_in.alloc(rx->scan_blocks_cap);
             rc |= rx->d_cap_block_off.alloc(caps + 1);
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
