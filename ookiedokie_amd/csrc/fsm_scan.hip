@@ -1513,14 +1513,21 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
 }
 
 // gathers payload bits: one lane per message, then one per capture for the outgoing state
-__global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
+// Last kernel of the scan: resolves the payloads and, with `pp`, also does the
+// publish step (edges_fsm.hip: publish_kernel) -- resolved messages go to the
+// host copy as they are produced, the workgroup that finishes last copies the
+// header and zeroes the device one.
+__global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp, PublishParams pp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
-    if (*sp.fallback) return;
+    __shared__ uint32_t s_last;
+    const bool refused = *sp.fallback != 0;
     const uint32_t max_bits = sp.f.tables->max_bits;
     const uint32_t nbytes = (max_bits + 7u) >> 3;
-    const uint64_t nmsg = min((uint64_t)sp.f.totals[0], sp.f.msg_capacity);
+    const uint64_t nmsg = refused ? 0 : min((uint64_t)sp.f.totals[0], sp.f.msg_capacity);
+    const uint64_t nitems = refused ? 0 : nmsg + sp.f.num_captures;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nmsg + sp.f.num_captures; m += stride) {
+    MsgDev *h_msgs = reinterpret_cast<MsgDev *>(pp.h_msgs);
+    for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nitems; m += stride) {
         if (m < nmsg) {
             MsgDev mm = sp.f.msgs[m];
             uint64_t e0;
@@ -1553,6 +1560,7 @@ __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
                 mm.payload[q] = v;
             }
             sp.f.msgs[m] = mm;
+            if (h_msgs && m < pp.first_msgs) h_msgs[m] = mm;
         } else {
             const uint32_t cap = (uint32_t)(m - nmsg);
             SegState so = sp.final_state[cap];
@@ -1568,6 +1576,20 @@ __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp) {
             sp.final_state[cap] = so;
         }
     }
+    if (!pp.d_hdr) return;
+    // ---- publish: the last workgroup to get here owns the header ----------------------------
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(pp.d_hdr + pp.done_word, 1u) + 1u == gridDim.x ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid < pp.hdr_words) {
+        uint32_t v = pp.d_hdr[tid];
+        if (tid == pp.edges_word && pp.total_edges) v = *pp.total_edges;
+        pp.h_hdr[tid] = v;
+    }
+    __syncthreads();
+    if (tid < pp.hdr_words) pp.d_hdr[tid] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -1822,7 +1844,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
-    hipLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, sp);
+    hipLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, sp, a.publish);
     return hipGetLastError();
 }
 

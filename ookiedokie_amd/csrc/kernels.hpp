@@ -191,6 +191,7 @@ struct PublishParams {
     const uint4 *d_msgs;            // or null (no state machine)
     uint4 *h_msgs;
     uint64_t first_msgs;            // messages published with the header
+    uint32_t done_word;             // dword index of a zero-initialised completion counter (multi-workgroup publishers)
 };
 hipError_t launch_publish(const PublishParams &p, hipStream_t stream);
 
@@ -220,6 +221,7 @@ struct FsmScanArgs {
     uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
+    PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]

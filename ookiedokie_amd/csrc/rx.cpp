@@ -44,7 +44,7 @@ struct ResultHeader {
     uint32_t total_edges;
     uint32_t scan_fallback;
     uint32_t fin_ticket;        // work counter of the scan's finish kernel
-    uint32_t pad;
+    uint32_t publish_done;      // workgroups of the scan's publishing kernel that are through
 };
 
 // Front-end kernels of different contexts on one device take turns: they are
@@ -479,6 +479,8 @@ struct ookd_rx {
     int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
     int fetch_results();
     int enqueue_publish();
+    PublishParams publish_params() const;
+    bool scan_published = false;    // the queued scan ends with the publish step
     int collect_results();
     bool submitted = false;         // a run is queued (ookd_rx_submit_device) and not yet waited for
 };
@@ -620,6 +622,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_n0 = d_lt_n0.p;
     a.lt_pk = d_lt_pk.p;
     a.ltab = d_ltab.p;
+    a.publish = publish_params();
     a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
@@ -644,6 +647,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.fin_blocks_cap = scan_fin_cap;
     // totals / scan_fallback are still zero from the header memset of front_and_edges
     HIPCHK(launch_fsm_scan(a, stream));
+    scan_published = true;          // its last kernel also publishes
     HIPCHK(hipEventRecord(ev[2], stream));
     static const char *const debug_scan = getenv("OOKD_DEBUG_SCAN");     // read once: this is the hot path
     if (debug_scan) HIPCHK(hipStreamSynchronize(stream));
@@ -681,25 +685,32 @@ int ookd_rx::fetch_results() {
     return collect_results();
 }
 
-// Last kernel of a run: header and first messages into pinned host memory.
-int ookd_rx::enqueue_publish() {
-    const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
-    {
-        static_assert(sizeof(ResultHeader) % 4 == 0 && sizeof(ResultHeader) / 4 <= 256, "header is published by one workgroup");
-        PublishParams pp{};
-        pp.d_hdr = reinterpret_cast<uint32_t *>(d_hdr.p);
-        pp.h_hdr = reinterpret_cast<uint32_t *>(h_hdr_dev);
-        pp.hdr_words = sizeof(ResultHeader) / 4;
-        pp.totals_word = offsetof(ResultHeader, totals) / 4;
-        pp.edges_word = offsetof(ResultHeader, total_edges) / 4;
-        pp.total_edges = run_n_out > 0 ? d_blk_offset.p + (size_t)run_caps * run_blocks : nullptr;
-        if (have_fsm && run_n_out > 0) {
-            pp.d_msgs = reinterpret_cast<const uint4 *>(d_msgs.p);
-            pp.h_msgs = reinterpret_cast<uint4 *>(h_msgs_dev);
-        }
-        pp.first_msgs = first;
-        HIPCHK(launch_publish(pp, stream));
+PublishParams ookd_rx::publish_params() const {
+    static_assert(sizeof(ResultHeader) % 4 == 0 && sizeof(ResultHeader) / 4 <= 256, "header is published by one workgroup");
+    PublishParams pp{};
+    pp.d_hdr = reinterpret_cast<uint32_t *>(d_hdr.p);
+    pp.h_hdr = reinterpret_cast<uint32_t *>(h_hdr_dev);
+    pp.hdr_words = sizeof(ResultHeader) / 4;
+    pp.totals_word = offsetof(ResultHeader, totals) / 4;
+    pp.edges_word = offsetof(ResultHeader, total_edges) / 4;
+    pp.done_word = offsetof(ResultHeader, publish_done) / 4;
+    pp.total_edges = run_n_out > 0 ? d_blk_offset.p + (size_t)run_caps * run_blocks : nullptr;
+    if (have_fsm && run_n_out > 0) {
+        pp.d_msgs = reinterpret_cast<const uint4 *>(d_msgs.p);
+        pp.h_msgs = reinterpret_cast<uint4 *>(h_msgs_dev);
     }
+    pp.first_msgs = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
+    return pp;
+}
+
+// Last kernel of a run: header and first messages into pinned host memory (the
+// scan form's last kernel has already done it).
+int ookd_rx::enqueue_publish() {
+    if (scan_published) {
+        scan_published = false;
+        return OOKD_OK;
+    }
+    HIPCHK(launch_publish(publish_params(), stream));
     return OOKD_OK;
 }
 
