@@ -453,6 +453,8 @@ struct ScanParams {
     // length, per (row, level); null = simulate
     const uint32_t *lt_off, *lt_n0, *lt_pk;
     const void *ltab;           // device copy of the LTab (fsm_scan_fill_ltab)
+    const uint16_t *reach;      // abstract codes a span can be entered in (from the span tables), or null = all
+    uint32_t nreach;
     uint32_t Dp;                // block table row pitch (D rounded up to 8)
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -887,20 +889,29 @@ __device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const uint64
 
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
 __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
-                               const uint16_t (*skip)[2]) {
+                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach) {
     const uint32_t nch = (count + kChunk - 1) / kChunk;
-    const uint32_t nitem = nch * D;
+    // Only the codes a span can actually be entered in are walked (reach[], the
+    // closure of the span tables' results); every other entry is poison, so a
+    // path that leaves the closure after all makes the capture fall back.
+    const uint32_t NR = reach ? nreach : D;
+    if (reach) {
+        for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
+        __syncthreads();
+    }
+    const uint32_t nitem = nch * NR;
     // An item is a chain of up to 16 dependent LDS reads; a lane walks kIlp
     // independent items side by side so that their latencies overlap.
     constexpr int kIlp = 5;
     for (uint32_t base = threadIdx.x; base < nitem; base += blockDim.x * kIlp) {
-        uint32_t st[kIlp], l0[kIlp], l1[kIlp];
+        uint32_t st[kIlp], l0[kIlp], l1[kIlp], dst[kIlp];
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
             const uint32_t item = base + j * blockDim.x;
             const uint32_t it = item < nitem ? item : 0u;
-            const uint32_t c = it / D;
-            st[j] = it - c * D;
+            const uint32_t c = it / NR, idx = it - c * NR;
+            st[j] = reach ? (uint32_t)reach[idx] : idx;
+            dst[j] = c * D + st[j];
             l0[j] = c * kChunk;
             l1[j] = item < nitem ? min((c + 1) * kChunk, count) : l0[j];
         }
@@ -914,7 +925,7 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
             const uint32_t item = base + j * blockDim.x;
-            if (item < nitem) b.ctab[item] = (uint16_t)st[j];
+            if (item < nitem) b.ctab[dst[j]] = (uint16_t)st[j];
         }
     }
     __syncthreads();
@@ -1010,7 +1021,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         }
         block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        compose_chunks(b, D, T.S * T.NB1, count, s_rep, s_skip);
+        compose_chunks(b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach);
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;
@@ -1713,8 +1724,67 @@ void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &g, uint32_t spb, uint32_t
     fill_ltab_host(*static_cast<LTab *>(dst), g, spb, decim);
 }
 
+// Abstract codes a span can be entered in: closure of {reset, skip x2, poison} under every
+// result the span tables hold (any length, either level).  Entries that need a
+// simulation add nothing: they are spans with an error before their last sample, which
+// end either skipping or as a run from (reset, no bits) at a buffer start with the
+// previous level equal to the span's -- a result of row (reset, few bits) again.
+// Empty = unknown (a bit-count sensitive result): the kernels then compose over all
+// codes.  (A code missed here would only cost speed: its entries are poison, and a
+// poisoned capture falls back to the rounds.)
+static void reachable_codes(const LTab &T, const std::vector<uint32_t> &off, const std::vector<uint32_t> &pk,
+                            std::vector<uint16_t> &reach) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D;
+    std::vector<char> in(D, 0);
+    std::vector<uint32_t> todo;
+    auto add = [&](uint32_t code) {
+        if (code < D && !in[code]) {
+            in[code] = 1;
+            todo.push_back(code);
+        }
+    };
+    // results of table (row, L) entered with nb bits; false = unknown
+    auto follow = [&](uint32_t row, uint32_t nb) {
+        for (uint32_t L = 0; L < 2; ++L) {
+            for (uint32_t i = off[2 * row + L]; i < off[2 * row + L + 1]; ++i) {
+                const uint32_t v = pk[i];
+                if (v & kPkAbsolute) {
+                    add(v & 0xffffu);
+                } else if (v & kPkRelative) {
+                    const uint32_t nbo = nb + ((v >> 8) & 0xffffu);
+                    add((v & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo));
+                } else if (v & kPkSensitive) {
+                    return false;
+                }
+            }
+        }
+        return true;
+    };
+    reach.clear();
+    add(0);
+    add(SNB);
+    add(SNB + 1);
+    add(SNB + 2);
+    while (!todo.empty()) {
+        const uint32_t code = todo.back();
+        todo.pop_back();
+        if (code == SNB + 2) continue;
+        bool known;
+        if (code >= SNB) {
+            known = follow(2 * S + (code - SNB), 0u);           // skipping ends inside a span of the other level
+        } else {
+            const uint32_t cur = code / NB1, nb = code - cur * NB1;
+            known = follow(2 * cur + (nb >= T.max_bits ? 1u : 0u), nb);
+        }
+        if (!known) return;
+    }
+    for (uint32_t c = 0; c < D; ++c) {
+        if (in[c]) reach.push_back((uint16_t)c);
+    }
+}
+
 bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
-                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk) {
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach) {
     std::unique_ptr<LTab> Tp(new LTab());
     LTab &T = *Tp;
     fill_ltab_host(T, g, spb, decim);
@@ -1774,6 +1844,7 @@ bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std:
         }
     }
     off[2 * rows] = (uint32_t)n0.size();
+    reachable_codes(T, off, pk, reach);
     return true;
 }
 
@@ -1818,6 +1889,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     sp.lt_n0 = a.lt_n0;
     sp.lt_pk = a.lt_pk;
     sp.ltab = a.ltab;
+    // with a concrete incoming state (shards) the first span may leave the closure: no pruning
+    sp.reach = a.first ? nullptr : a.reach;
+    sp.nreach = a.first ? 0 : a.nreach;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;

@@ -222,6 +222,8 @@ struct FsmScanArgs {
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
     PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
+    const uint16_t *reach;      // codes a span can be entered in, or null = all
+    uint32_t nreach;
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]
@@ -251,8 +253,10 @@ size_t fsm_scan_ltab_bytes();
 void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &tables, uint32_t spb, uint32_t decim);
 // Packed result of a span as a step function of its length, per (row, level)
 // (host side; false = not tabulated, the kernels simulate).
+// reach: the abstract codes a span can be entered in (closure of the tables' results);
+// empty when that cannot be told.
 bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
-                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk);
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach);
 uint32_t fsm_scan_fin_block();
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 

@@ -301,6 +301,7 @@ struct ookd_rx {
     DevBuf<uint16_t> d_block_tab, d_chunk_tab;
     DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
     DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
+    DevBuf<uint16_t> d_reach;       // abstract codes a span can be entered in (empty = all)
     DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
@@ -359,6 +360,7 @@ struct ookd_rx {
         d_lt_n0.release();
         d_lt_pk.release();
         d_ltab.release();
+        d_reach.release();
         d_leaf_res.release();
         d_cap_group_off.release();
         d_group_tab.release();
@@ -622,6 +624,8 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_n0 = d_lt_n0.p;
     a.lt_pk = d_lt_pk.p;
     a.ltab = d_ltab.p;
+    a.reach = d_reach.p;
+    a.nreach = (uint32_t)d_reach.n;
     a.publish = publish_params();
     a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
@@ -990,13 +994,15 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         if (rx->scan_ok && !(cfg->flags & OOKD_RX_SCAN_SIMS)) {
             // span tables: packed result of a span as a step function of its length
             std::vector<uint32_t> off, n0, pk;
+            std::vector<uint16_t> reach;
             const auto t0 = std::chrono::steady_clock::now();
-            const bool ok = build_leaf_tables(*rx->h_tables, cfg->samples_per_buffer, rx->total_decim, off, n0, pk);
+            const bool ok = build_leaf_tables(*rx->h_tables, cfg->samples_per_buffer, rx->total_decim, off, n0, pk,
+                                              reach);
             if (getenv("OOKD_DEBUG")) {
                 size_t zeros = 0;
                 for (uint32_t v : pk) zeros += v == 0;
-                fprintf(stderr, "[ookd] span tables: %s, %zu intervals (%zu need simulation), %.1f ms\n",
-                        ok ? "built" : "REFUSED", n0.size(), zeros,
+                fprintf(stderr, "[ookd] span tables: %s, %zu intervals (%zu need simulation), %zu of %u codes reachable, %.1f ms\n",
+                        ok ? "built" : "REFUSED", n0.size(), zeros, reach.size(), rx->scan_D,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 if (getenv("OOKD_DEBUG")[0] == '2') {
                     for (size_t t = 0; t + 1 < off.size(); ++t) {
@@ -1004,6 +1010,12 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                         for (uint32_t i = off[t]; i < off[t + 1]; ++i) fprintf(stderr, " %u:%08x", n0[i], pk[i]);
                         fprintf(stderr, "\n");
                     }
+                }
+            }
+            if (ok && !reach.empty()) {
+                rc |= rx->d_reach.alloc(reach.size());
+                if (rc == OOKD_OK && hipMemcpy(rx->d_reach.p, reach.data(), reach.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+                    rc = OOKD_ERR_HIP;
                 }
             }
             if (ok && !n0.empty()) {
