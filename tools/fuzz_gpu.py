@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Randomised differential run on the GPU box: HIP path (scan with span tables, scan with
+per-span simulation, rounds) against the CPU oracle on message-like streams whose run
+lengths sit on and around the devices' tolerance windows, with glitches, for several sample
+rates and buffer sizes.  Not part of the test suite (minutes); prints a JSON summary.
+
+    python tools/fuzz_gpu.py [--seconds 300] [--seed 1]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import ookiedokie_amd as ok          # noqa: E402
+import oracle as O                   # noqa: E402  (checker)
+from tests.helpers import golden_path, stream_from_runs   # noqa: E402
+
+# canonical run lengths in microseconds: lead, start pulse, first gap, pulse, gap0, gap1
+SHAPES = {
+    "p3l-nexa2012": dict(bits=36, start=500, first=8700, pulse=500, gap0=2000, gap1=4000),
+    "unknown-remote1": dict(bits=32, start=8900, first=4400, pulse=550, gap0=550, gap1=1700),
+}
+
+
+def jitter(rng, us, rate, mode):
+    n = us * rate / 1e6
+    if mode == 0:
+        f = 1.0
+    elif mode == 1:                              # around the +-15 % window edges
+        f = rng.choice([0.85, 1.15]) + rng.uniform(-0.004, 0.004)
+    elif mode == 2:
+        f = rng.uniform(0.8, 1.2)
+    else:
+        f = rng.uniform(0.3, 3.0)
+    return max(1, int(round(n * f)))
+
+
+def message_runs(rng, shape, rate):
+    p_bad = rng.choice([0.0, 0.02, 0.1])
+    def j(us):
+        r = rng.random()
+        mode = 0 if r >= p_bad else int(rng.integers(1, 4))
+        return jitter(rng, us, rate, mode)
+    runs = [j(shape["start"]), j(shape["first"])]
+    nbits = shape["bits"] if rng.random() < 0.8 else int(rng.integers(1, shape["bits"] + 8))
+    for _ in range(nbits):
+        runs += [j(shape["pulse"]), j(shape["gap1"] if rng.random() < 0.5 else shape["gap0"])]
+    runs += [j(shape["pulse"])]
+    return runs
+
+
+def capture_runs(rng, shape, rate):
+    runs = [int(rng.integers(1, 20000))]         # leading off time
+    for _ in range(int(rng.integers(1, 7))):
+        if rng.random() < 0.3:                   # glitch pulse before the message
+            runs += [max(1, int(rng.integers(1, 400) * rate / 3e6)), max(1, int(rng.integers(100, 9000) * rate / 3e6))]
+        runs += message_runs(rng, shape, rate)
+        gap_us = rng.choice([300, 1000, 4000, 12000, 20000]) * rng.uniform(0.8, 1.3)
+        runs += [max(1, int(gap_us * rate / 1e6))]
+    return runs
+
+
+def iq_from_stream(stream, rng, noise):
+    iq = np.zeros(2 * stream.size, dtype=np.int16)
+    iq[0::2] = stream.astype(np.int16) * 1945
+    if noise:
+        iq = (iq + rng.integers(-40, 41, size=iq.size)).astype(np.int16)
+    return iq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    stats = dict(cases=0, receivers=0, messages=0, errors=0, scan_runs=0, scan_refused=0, refusals={}, mismatches=[])
+    flts = {None: (None, None)}
+    for name in ("fs32_fs4", "fs128_fs16_dec4"):
+        flts[name] = (ok.Filter.load(golden_path("filters", name)), O.load_filter_json(golden_path("filters", name)))
+    last = time.time()
+    while time.time() < t_end and len(stats["mismatches"]) < 5:
+        name = str(rng.choice(list(SHAPES)))
+        rate = int(rng.choice([3000000, 2000000, 1000000, 750000, 250000]))
+        fname = rng.choice([None, None, "fs32_fs4", "fs128_fs16_dec4"])
+        fname = None if fname is None else str(fname)
+        f, of = flts[fname]
+        dec = of.total_decimation if of else 1
+        runs = capture_runs(rng, SHAPES[name], rate)
+        stream = stream_from_runs(runs)
+        if stream.size > 3_000_000:
+            continue
+        iq = iq_from_stream(stream, rng, noise=fname is not None)
+        d = ok.Device.load(golden_path("devices", name), rate // dec)
+        od, _ = O.load_device_json(golden_path("devices", name), rate // dec)
+        spb = int(rng.choice([97, 1000, 4096, 8192, 65536]))
+        if dec > 1:
+            spb = max(dec, spb - spb % dec)
+        want = O.rx(iq, of, 0.1, od, spb, want_bits=True)
+        stats["cases"] += 1
+        stats["messages"] += len(want.msg_samples)
+        stats["errors"] += len(want.err_samples)
+        for fsm_rounds, scan_sims in ((False, False), (False, True), (True, False)):
+            rx = ok.Receiver(f, d, max_samples=iq.size // 2, samples_per_buffer=spb, fsm_rounds=fsm_rounds,
+                             quiet_skip=not fsm_rounds, scan_sims=scan_sims)
+            got = rx.rx(iq)
+            stats["receivers"] += 1
+            if not fsm_rounds:
+                stats["scan_runs"] += 1
+                if got.stats["fsm_path"] != 1:
+                    stats["scan_refused"] += 1
+                    key = "reason %#x spb %d%s" % (got.stats["fsm_fallback_reason"], spb, " sims" if scan_sims else "")
+                    stats["refusals"][key] = stats["refusals"].get(key, 0) + 1
+            errs, nerr = rx.errors()
+            good = ((rx.bits() == want.bits).all() and list(got.msg_samples) == list(want.msg_samples)
+                    and (got.payloads == want.payloads).all() and nerr == len(want.err_samples)
+                    and (nerr > 32 or list(errs) == list(want.err_samples)))
+            if not good:
+                stats["mismatches"].append(dict(device=name, rate=rate, filter=fname, spb=spb, runs=[int(r) for r in runs],
+                                                fsm_rounds=fsm_rounds, scan_sims=scan_sims,
+                                                want=[int(x) for x in want.msg_samples],
+                                                got=[int(x) for x in got.msg_samples]))
+            rx.close()
+        if time.time() - last > 30:
+            last = time.time()
+            print("[fuzz] %d cases, %d messages, %d fsm errors, %d mismatches" %
+                  (stats["cases"], stats["messages"], stats["errors"], len(stats["mismatches"])), file=sys.stderr, flush=True)
+    print(json.dumps(stats))
+    return 1 if stats["mismatches"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
