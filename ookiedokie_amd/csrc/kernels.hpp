@@ -18,10 +18,11 @@ constexpr int kFirR = 16;               // outputs per lane in the 1-stage kerne
 constexpr int kFirTile = kFirThreads * kFirR;   // 4096 outputs per workgroup
 constexpr int kFirWaves = kFirThreads / 64;     // 1024-output wave tiles per 4096-output block
 constexpr int kFirWgWaves = 1;                  // wave tiles per workgroup of the 1-stage kernel
-// outputs per lane of the 1-stage kernel (tile = 64 * R): short filters use small tiles (finer
-// quiet shortcut: -6 % on the bench capture), long ones the MAC-efficient large tile
+// outputs per lane of the 1-stage kernel (tile = 64 * R): with the quiet shortcut the small tile
+// (finer shortcut, smaller LDS window = more waves per CU: -6 % with 32 taps on the bench capture,
+// -8 % with 255 taps); without it the MAC-efficient large tile
 constexpr int kFir1RShort = 8, kFir1RLong = 16;
-constexpr uint32_t kFir1ShortTaps = 64;         // padded tap count up to which the small tile is used
+constexpr uint32_t kFir1ShortTaps = 256;        // padded tap count up to which the small tile is used (all)
 constexpr int kWaveTile = 64 * kFirR;           // 1024 outputs per wavefront
 constexpr int kQuietCounters = 1024;
 constexpr int kGenTile = 1024;          // final outputs per workgroup, generic kernel
