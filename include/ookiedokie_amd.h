@@ -277,6 +277,16 @@ int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in,
                          ookd_fsm_state *state_out);
 uint64_t ookd_rx_halo_samples(const ookd_rx *rx);
 
+/* Diagnostic, host only (no GPU): the abstract domain the scan form of the
+ * state machine would use for this device at this rate / buffer size.
+ * out = { span tables built (0/1), table intervals, intervals that need a
+ * simulation, reachable codes (0 = unknown), normal codes that can get
+ * "stuck" (an edge on which no trigger fires), table rows holding such a
+ * result, domain size, machine states }. */
+int ookd_scan_domain_info(const ookd_device *device,
+                          uint32_t samples_per_buffer,
+                          uint32_t total_decimation, uint32_t out[8]);
+
 /* Results of the last run (host copies, valid until the next run). */
 uint64_t ookd_rx_num_messages(const ookd_rx *rx);
 const ookd_message *ookd_rx_messages(const ookd_rx *rx);

@@ -160,6 +160,7 @@ _PROTOTYPES = {
     "ookd_rx_destroy": (None, [C.c_void_p]),
     "ookd_rx_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "ookd_rx_submit_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ookd_scan_domain_info": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "ookd_rx_wait": (C.c_int, [C.c_void_p]),
     "ookd_rx_process_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "ookd_rx_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,

@@ -51,6 +51,14 @@ constexpr uint32_t kSat = 0xfffffffeu;
 constexpr uint32_t kMaxFires = 48;      // trigger firings simulated per span before giving up
 constexpr uint32_t kMaxLeafApps = 30;
 constexpr int kScanThreads = 1024;
+// "Stuck" codes: an edge on which no trigger fires, in a state whose counter matters,
+// leaves the machine outside (state, bit count).  But nothing fired, so the span simply
+// goes on: STUCK_d(s) = "entered d leaves ago in normal state s, no trigger fired on the
+// d edges since" -- the next leaf is row(s) evaluated at the merged length.
+constexpr uint32_t kStuckDepth = 8;     // inert edges in a row that stay representable, at most (LTab.depth)
+constexpr uint32_t kStuckDomain = 384;  // the stuck codes may grow the domain up to this size
+constexpr uint32_t kMaxStuck = 256;     // normal codes that can get stuck (p3l-nexa2012: 37)
+constexpr uint32_t kMaxStuckRows = 32;
 
 // reasons in the fallback word
 enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8 };
@@ -62,8 +70,12 @@ enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8 };
 struct LTab {
     uint4 st[kMaxStates];       // kmin, kmax, kto, row = tbeg | tend << 8 | k-free << 16 | has msg_complete << 17
     uint4 tr[kMaxTriggers];     // kmin, kmax, info = cond | action << 8 | next << 16, -
-    uint32_t max_bits, S, NB1, D;       // NB1 = max_bits + 2 bit-count values; D = S*NB1 + 3
+    uint32_t max_bits, S, NB1, D;       // NB1 = max_bits + 2 bit-count values; D = S*NB1 + 3 + stuck codes
     uint32_t spb, decim;
+    uint32_t NS, nstuck_rows;           // stuck codes: S*NB1 + 3 + (d-1)*NS + index in stuck_src
+    uint32_t depth, pad_;               // d = 1 .. depth <= kStuckDepth
+    uint16_t stuck_src[kMaxStuck];      // ascending: the normal codes that can get stuck
+    uint8_t stuck_row[kMaxStuckRows];   // row | level << 7: span-table rows with a stuck result, met at that level
 };
 
 __host__ __device__ __forceinline__ uint32_t clamp32(uint64_t v) { return v == ~0ull ? kNone : (uint32_t)v; }
@@ -88,6 +100,7 @@ struct Acc {
     uint32_t out_ab0, out_ab1, out_rb0, out_rb1;
     uint64_t out_pos0, out_pos1, err_pos;
     bool reset_seen, sensitive, overflow, msgc_seen;
+    bool last_fired;            // a trigger fired on the last sample that was run
 };
 
 __host__ __device__ __forceinline__ void acc_init(Acc &a) {
@@ -98,6 +111,7 @@ __host__ __device__ __forceinline__ void acc_init(Acc &a) {
     a.out_pos0 = a.out_pos1 = 0;
     a.err_pos = 0;
     a.reset_seen = a.sensitive = a.overflow = a.msgc_seen = false;
+    a.last_fired = false;
 }
 
 __host__ __device__ __forceinline__ uint32_t sat_add(uint32_t k, uint64_t m) {
@@ -277,6 +291,7 @@ __host__ __device__ __forceinline__ bool sim_span(const LTab &T, PSim &f, Acc &a
             if (m > 0) {
                 canon(T, f);
                 pos += m;
+                a.last_fired = false;
                 continue;
             }
         }
@@ -284,7 +299,9 @@ __host__ __device__ __forceinline__ bool sim_span(const LTab &T, PSim &f, Acc &a
             a.overflow = true;
             return true;
         }
+        const uint32_t fires0 = a.fires;
         const int r = p_step(T, f, a, b, pos);
+        a.last_fired = a.fires != fires0;
         f.prev = b;
         canon(T, f);
         if (r == kResError) {
@@ -303,6 +320,7 @@ struct Span {                   // the samples a leaf covers
     uint64_t pos0, n;
     uint32_t L;
     bool has_edge;
+    uint64_t prefix;            // entered stuck: samples before pos0 since the state was last normal
 };
 
 // leaf i (1 <= i < ne): samples e[i-1]+1 .. e[i]
@@ -312,6 +330,7 @@ __device__ __forceinline__ Span span_of(const uint64_t *edges, uint64_t i) {
     s.n = edges[i] - edges[i - 1] - 1;
     s.L = (uint32_t)(i & 1ull);         // level after edge i-1
     s.has_edge = true;
+    s.prefix = 0;
     return s;
 }
 
@@ -334,7 +353,8 @@ struct SimRes {
 __host__ __device__ __forceinline__ SimRes sim_pack(const PSim &f, const Acc &a, bool alive) {
     SimRes r;
     r.w[0] = (f.cur & 0xffu) | ((f.prev & 1u) << 8) | ((alive ? 1u : 0u) << 9) | ((a.reset_seen ? 1u : 0u) << 10) |
-             ((a.sensitive ? 1u : 0u) << 11) | ((a.overflow ? 1u : 0u) << 12) | ((a.msgc_seen ? 1u : 0u) << 13);
+             ((a.sensitive ? 1u : 0u) << 11) | ((a.overflow ? 1u : 0u) << 12) | ((a.msgc_seen ? 1u : 0u) << 13) |
+             ((a.last_fired ? 1u : 0u) << 14);
     r.w[1] = f.k;
     r.w[2] = f.nbits;
     r.w[3] = (a.napp > 255u ? 255u : a.napp) | ((a.nout > 255u ? 255u : a.nout) << 8) |
@@ -359,6 +379,7 @@ __host__ __device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Ac
     a.reset_seen = (r.w[0] >> 10) & 1u;
     a.sensitive = (r.w[0] >> 11) & 1u;
     a.overflow = (r.w[0] >> 12) & 1u;
+    a.last_fired = (r.w[0] >> 14) & 1u;
     a.msgc_seen = (r.w[0] >> 13) & 1u;
     a.napp = r.w[3] & 0xffu;
     a.nout = (r.w[3] >> 8) & 0xffu;
@@ -381,7 +402,7 @@ __host__ __device__ __forceinline__ bool sim_unpack(const SimRes &r, PSim &f, Ac
 // starts feeding samples again).  alive = false: ends inside a skip.  Must not
 // be called with the poison code.  lvl_edge = level | has_edge << 1.
 __host__ __device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t code, uint64_t pos0, uint64_t n, uint32_t lvl_edge,
-                                            uint64_t resume) {
+                                            uint64_t resume, uint64_t prefix = 0) {
     const uint32_t NB1 = T.NB1;
     const uint32_t nstates = T.S * NB1;
     const uint32_t L = lvl_edge & 1u;
@@ -405,7 +426,16 @@ __host__ __device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t cod
         f.nbits = code - f.cur * NB1;
         f.k = 0;
         f.prev = L;
+        bool lost = false;
+        if (prefix) {
+            // entered stuck: no trigger fired on the edges inside the prefix, so the machine
+            // went through it as through a constant level; what happened there belongs to
+            // the leaves before
+            lost = !sim_span(T, f, a, pos0 - prefix, L, prefix, false) || a.overflow;
+            acc_init(a);
+        }
         alive = sim_span(T, f, a, pos0, L, n, has_edge);
+        if (lost) a.overflow = true;
     }
     // the 8-bit event counters of the record saturate; more than the record can
     // hold is an overflow anyway (kMaxLeafApps, two outputs, one error)
@@ -414,7 +444,7 @@ __host__ __device__ __noinline__ SimRes run_leaf_raw(const LTab &T, uint32_t cod
 
 __device__ __forceinline__ bool run_leaf(const LTab &T, uint32_t code, const Span &sp, uint64_t resume, PSim &f,
                                          Acc &a) {
-    const SimRes r = run_leaf_raw(T, code, sp.pos0, sp.n, sp.L | (sp.has_edge ? 2u : 0u), resume);
+    const SimRes r = run_leaf_raw(T, code, sp.pos0, sp.n, sp.L | (sp.has_edge ? 2u : 0u), resume, sp.prefix);
     return sim_unpack(r, f, a);
 }
 
@@ -454,8 +484,8 @@ struct ScanParams {
     const uint32_t *lt_off, *lt_n0, *lt_pk;
     const void *ltab;           // device copy of the LTab (fsm_scan_fill_ltab)
     const uint16_t *reach;      // abstract codes a span can be entered in (from the span tables), or null = all
-    uint32_t nreach;
-    uint32_t Dp;                // block table row pitch (D rounded up to 8)
+    uint32_t nreach, nreach_base;       // all of them / the normal, skip and poison codes among them (they come first)
+    uint32_t Dp, D;             // block table row pitch (D rounded up to 8); D = the domain with the stuck codes
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
     uint16_t *group_in;         // [groups]
@@ -492,6 +522,7 @@ constexpr uint32_t kPkAbsolute = 0x80000000u;   // [15:0] end code, [23:16] its 
 constexpr uint32_t kPkSensitive = 0x40000000u;
 constexpr uint32_t kPkRelative = 0x20000000u;   // [7:0] end state, [23:8] appended bits
 constexpr uint32_t kPkShared = 0x10000000u;     // transient: class "all bits" takes this result too
+constexpr uint32_t kPkStuck = 0x08000000u;      // no trigger fired on the edge, the counter runs on
 
 __host__ __device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
     return code | ((code / NB1) << 16) | kPkAbsolute;
@@ -504,7 +535,9 @@ __host__ __device__ __forceinline__ uint32_t pack_normal(const LTab &T, const PS
     const uint32_t NB1 = T.NB1;
     const uint32_t out = encode_post(T, f, a, alive);
     uint32_t packed;
-    if (out >= T.S * NB1) {
+    if (!a.overflow && alive && !a.sensitive && !a.last_fired && f.k != 0 && !(T.st[f.cur].w & 0x10000u)) {
+        packed = kPkStuck;                                  // see kStuckDepth
+    } else if (out >= T.S * NB1) {
         packed = pack_absolute(out, NB1);                   // skip / poison
     } else if (a.sensitive) {
         packed = kPkSensitive;                              // row needs one simulation per bit count
@@ -537,12 +570,75 @@ __device__ __forceinline__ uint32_t lt_lookup(const uint32_t *off, const uint32_
     return pk[lo];
 }
 
+// ---- stuck codes (kStuckDepth) ---------------------------------------------------------
+struct StuckCtx {
+    const uint64_t *edges;                      // the capture's edge list
+    const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables (null: stuck stays poison)
+};
+
+// normal code s got stuck on the edge of its leaf: STUCK_1(s), or poison if it is not in the domain
+__device__ __forceinline__ uint32_t stuck_enter(const LTab &T, const StuckCtx &c, uint32_t s) {
+    if (!c.lt_off) return code_poison(T);
+    uint32_t lo = 0, hi = T.NS;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (T.stuck_src[mid] < s) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < T.NS && T.stuck_src[lo] == s) ? T.S * T.NB1 + 3 + lo : code_poison(T);
+}
+
+__device__ __forceinline__ void stuck_decode(const LTab &T, uint32_t code, uint32_t &d, uint32_t &src) {
+    const uint32_t rel = code - (T.S * T.NB1 + 3);
+    d = rel / T.NS + 1;
+    src = T.stuck_src[rel - (d - 1) * T.NS];
+}
+
+// Leaf i (edge index in the capture) entered in a stuck code: no trigger fired on the d
+// edges before it, so the machine saw one span from the start of leaf i - d on: the row
+// of the code it had there, at the merged length, ended by this leaf's edge.
+__device__ __noinline__ uint32_t stuck_step(const LTab &T, const StuckCtx &c, uint64_t i, uint32_t code) {
+    const uint32_t NB1 = T.NB1;
+    if (!c.lt_off || !T.NS) return code_poison(T);
+    uint32_t d, src;
+    stuck_decode(T, code, d, src);
+    if (i < (uint64_t)d + 1) return code_poison(T);
+    const uint64_t n = c.edges[i] - c.edges[i - d - 1] - 1;
+    if (n > 0xfffffff0ull) return code_poison(T);
+    const uint32_t cur = src / NB1, nb = src - cur * NB1;
+    const uint32_t pk = lt_lookup(c.lt_off, c.lt_n0, c.lt_pk, 2 * cur + (nb >= T.max_bits ? 1u : 0u),
+                                  (uint32_t)(i & 1ull), (uint32_t)n);
+    if (pk & kPkAbsolute) return pk & 0xffffu;
+    if (pk & kPkRelative) {
+        const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+        return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+    }
+    if ((pk & kPkStuck) && d < T.depth) return code + T.NS;
+    return code_poison(T);              // deeper, position dependent or bit-count sensitive: not followed
+}
+
+// the span of leaf i as the simulator has to run it when the leaf is entered in `code`
+__device__ __forceinline__ Span span_entered(const LTab &T, const uint64_t *edges, uint64_t i, uint32_t &code) {
+    Span sp = span_of(edges, i);
+    if (code >= T.S * T.NB1 + 3) {
+        uint32_t d, src;
+        stuck_decode(T, code, d, src);
+        sp.prefix = edges[i - 1] - edges[i - d - 1];
+        code = src;
+    }
+    return sp;
+}
+
+constexpr uint32_t kCapWords = (256 + kStuckDepth + 31) / 32;
+constexpr uint32_t kLtLdsWords = 768;   // span tables up to this size are searched from LDS (shipped devices: 409)
 #define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// cap: bit kStuckDepth + l = leaf l of the block (l = -kStuckDepth .. count-1) can end stuck
 __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
                            uint64_t *resume, uint16_t *rep /* [count] */, uint16_t *uniq /* [count + 1] */,
                            const uint32_t *lt_off, const uint32_t *lt_n0, const uint32_t *lt_pk,
-                           uint64_t *dbg = nullptr) {
+                           uint32_t *cap /* [kCapWords] */, uint64_t *dbg = nullptr) {
     STAMP(0);
+    for (uint32_t w = threadIdx.x; w < kCapWords; w += blockDim.x) cap[w] = 0;
     const uint32_t S = T.S, NB1 = T.NB1, max_bits = T.max_bits;
     const uint32_t nsim = 2 * S + 2;
     // one 64-bit division per leaf instead of one per simulation
@@ -730,6 +826,29 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         if (r != l) res[l * nsim + c] = res[r * nsim + c];
     }
     __syncthreads();
+    if (lt_off && T.NS) {
+        // which leaves can end stuck: those of the block from their rows, the few before it
+        // (whose stuck codes may enter the block) from the tables
+        // (only rows of states that can be met at the leaf's level count: stuck_row = row | level << 7)
+        for (uint32_t e = threadIdx.x; e < count * T.nstuck_rows; e += blockDim.x) {
+            const uint32_t l = e / T.nstuck_rows, rl = T.stuck_row[e - l * T.nstuck_rows];
+            if ((rl >> 7) != (uint32_t)((first + l) & 1ull)) continue;
+            if (res[l * nsim + (rl & 127u)] & kPkStuck) atomicOr(&cap[(l + kStuckDepth) >> 5], 1u << ((l + kStuckDepth) & 31u));
+        }
+        for (uint32_t t = threadIdx.x; t < T.depth * T.nstuck_rows; t += blockDim.x) {
+            const uint32_t j = t / T.nstuck_rows + 1, rl = T.stuck_row[t - (j - 1) * T.nstuck_rows];
+            const uint32_t r = rl & 127u;
+            if (first < (uint64_t)j + 1) continue;                  // leaf first - j >= 1
+            const uint64_t i = first - j;
+            if ((rl >> 7) != (uint32_t)(i & 1ull)) continue;
+            const uint64_t n = edges[i] - edges[i - 1] - 1;
+            if (n > 0xfffffff0ull) continue;
+            if (lt_lookup(lt_off, lt_n0, lt_pk, r, (uint32_t)(i & 1ull), (uint32_t)n) & kPkStuck) {
+                atomicOr(&cap[(kStuckDepth - j) >> 5], 1u << ((kStuckDepth - j) & 31u));
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // Phase B: tables.  Leaves with the same (level, length) share their normal
@@ -737,10 +856,10 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
 // only (a handful per block); the two skip entries are per leaf.  One step of
 // a walk through leaf l is then   code < S*NB1 ? tab[rep[l] * D + code]
 //                                               : skip[l][code - S*NB1]   (poison stays).
-__device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint16_t *tab,
-                             const uint32_t *res, const uint64_t *resume, const uint16_t *rep,
+__device__ void block_expand(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first, uint32_t count,
+                             uint16_t *tab, const uint32_t *res, const uint64_t *resume, const uint16_t *rep,
                              uint16_t (*skip)[2]) {
-    const uint32_t S = T.S, NB1 = T.NB1, D = T.D, max_bits = T.max_bits;
+    const uint32_t S = T.S, NB1 = T.NB1, max_bits = T.max_bits;
     const uint32_t nsim = 2 * S + 2;
     const uint32_t SNB = S * NB1;
     for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
@@ -765,6 +884,8 @@ __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t firs
                 uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
                 if (nbo >= NB1) nbo = NB1 - 1;
                 out = (pk & 0xffu) * NB1 + nbo;
+            } else if (pk & kPkStuck) {
+                out = stuck_enter(T, sc, e);
             } else {
                 // exact per-count simulation (rare)
                 PSim f;
@@ -772,18 +893,20 @@ __device__ void block_expand(const LTab &T, const uint64_t *edges, uint64_t firs
                 const bool alive = run_leaf(T, e, span_of(edges, first + l), resume[l], f, a);
                 out = encode_post(T, f, a, alive);
             }
-            tab[l * D + e] = (uint16_t)out;
+            tab[l * SNB + e] = (uint16_t)out;
         }
       }
     }
     __syncthreads();
 }
 
-// one leaf applied to an abstract state code
-__device__ __forceinline__ uint32_t leaf_step(const uint16_t *tab, const uint16_t *rep, const uint16_t (*skip)[2],
-                                              uint32_t D, uint32_t SNB, uint32_t l, uint32_t s) {
-    if (s < SNB) return tab[(uint32_t)rep[l] * D + s];
-    return s >= SNB + 2 ? s : skip[l][s - SNB];
+// one leaf (l-th of the block that starts at edge `first`) applied to an abstract state code
+__device__ __forceinline__ uint32_t leaf_step(const LTab &T, const StuckCtx &sc, uint64_t first, const uint16_t *tab,
+                                              const uint16_t *rep, const uint16_t (*skip)[2], uint32_t SNB,
+                                              uint32_t l, uint32_t s) {
+    if (s < SNB) return tab[(uint32_t)rep[l] * SNB + s];
+    if (s < SNB + 2) return skip[l][s - SNB];
+    return s == SNB + 2 ? s : stuck_step(T, sc, first + l, s);
 }
 
 __device__ __forceinline__ void locate_block(const ScanParams &sp, uint32_t gb, uint32_t &cap, uint32_t &lb) {
@@ -849,19 +972,26 @@ struct BlockLds {
     uint32_t *res;      // [LB][2S+2]
 };
 
-__device__ __forceinline__ BlockLds carve(uint32_t LB, uint32_t D) {
+// leaf tables hold the normal codes only (SNB = S * NB1); chunk tables the whole domain
+// (the leaf-table area also stages up to kGroup - 1 block tables in the emit kernel)
+__host__ __device__ __forceinline__ size_t leaf_tab_bytes(uint32_t LB, uint32_t D, uint32_t SNB) {
+    const size_t a = (size_t)LB * SNB * 2, g = (size_t)16 * ((D + 7u) & ~7u) * 2;
+    return ((a > g ? a : g) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ BlockLds carve(uint32_t LB, uint32_t D, uint32_t SNB) {
     BlockLds b;
     size_t off = 0;
     b.tab = reinterpret_cast<uint16_t *>(scan_smem + off);
-    off += ((size_t)LB * D * 2 + 15) & ~(size_t)15;
+    off += leaf_tab_bytes(LB, D, SNB);
     b.ctab = reinterpret_cast<uint16_t *>(scan_smem + off);
     off += ((size_t)((LB + kChunk - 1) / kChunk) * D * 2 + 15) & ~(size_t)15;
     b.res = reinterpret_cast<uint32_t *>(scan_smem + off);
     return b;
 }
 
-static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S) {
-    size_t off = ((size_t)LB * D * 2 + 15) & ~(size_t)15;
+static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S, uint32_t SNB) {
+    size_t off = leaf_tab_bytes(LB, D, SNB);
     off += ((size_t)((LB + kChunk - 1) / kChunk) * D * 2 + 15) & ~(size_t)15;
     off += (size_t)LB * (2 * S + 2) * 4;
     return off;
@@ -869,11 +999,15 @@ static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S) {
 
 // The same step from the packed class results alone (a few dozen steps per
 // block in the emit kernel: not worth a table).
-__device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t l,
-                                                     const uint32_t *res, const uint64_t *resume, uint32_t s) {
+__device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const StuckCtx &sc, const uint64_t *edges,
+                                                     uint64_t first, uint32_t l, const uint32_t *res,
+                                                     const uint64_t *resume, uint32_t s) {
     const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
     const uint32_t *row = res + l * (2 * S + 2);
-    if (s >= SNB) return s >= SNB + 2 ? s : (row[2 * S + (s - SNB)] & 0xffffu);
+    if (s >= SNB) {
+        if (s < SNB + 2) return row[2 * S + (s - SNB)] & 0xffffu;
+        return s == SNB + 2 ? s : stuck_step(T, sc, first + l, s);
+    }
     const uint32_t cur = s / NB1, nb = s - cur * NB1;
     const uint32_t pk = row[2 * cur + (nb >= T.max_bits ? 1u : 0u)];
     if (pk & kPkAbsolute) return pk & 0xffffu;
@@ -881,6 +1015,7 @@ __device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const uint64
         const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
         return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
     }
+    if (pk & kPkStuck) return stuck_enter(T, sc, s);
     PSim f;                     // row depends on the exact bit count (rare): simulate
     Acc a;
     const bool alive = run_leaf(T, s, span_of(edges, first + l), resume[l], f, a);
@@ -888,20 +1023,23 @@ __device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const uint64
 }
 
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
-__device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
-                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach) {
+__device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first, const uint32_t *cap,
+                               const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
+                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach_base) {
     const uint32_t nch = (count + kChunk - 1) / kChunk;
+    const uint32_t D0 = SNB + 3;
     // Only the codes a span can actually be entered in are walked (reach[], the
-    // closure of the span tables' results); every other entry is poison, so a
-    // path that leaves the closure after all makes the capture fall back.
-    const uint32_t NR = reach ? nreach : D;
-    if (reach) {
-        for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
-        __syncthreads();
-    }
+    // closure of the span tables' results; its first nreach_base entries are the
+    // normal / skip / poison codes); every other entry is poison, so a path that
+    // leaves the closure after all makes the capture fall back.
+    const uint32_t NR = reach ? nreach_base : D0;
+    // (without a reach list every normal / skip entry is computed below; the stuck ones rarely)
+    for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
+    __syncthreads();
     const uint32_t nitem = nch * NR;
     // An item is a chain of up to 16 dependent LDS reads; a lane walks kIlp
-    // independent items side by side so that their latencies overlap.
+    // independent items side by side so that their latencies overlap.  A chain that
+    // gets stuck (rare) stops here and is finished below, out of the unrolled loop.
     constexpr int kIlp = 5;
     for (uint32_t base = threadIdx.x; base < nitem; base += blockDim.x * kIlp) {
         uint32_t st[kIlp], l0[kIlp], l1[kIlp], dst[kIlp];
@@ -910,22 +1048,57 @@ __device__ void compose_chunks(const BlockLds &b, uint32_t D, uint32_t SNB, uint
             const uint32_t item = base + j * blockDim.x;
             const uint32_t it = item < nitem ? item : 0u;
             const uint32_t c = it / NR, idx = it - c * NR;
-            st[j] = reach ? (uint32_t)reach[idx] : idx;
+            const uint32_t rv = reach ? (uint32_t)reach[idx] : (idx | 0xc000u);
+            st[j] = rv & 0x3fffu;
             dst[j] = c * D + st[j];
             l0[j] = c * kChunk;
             l1[j] = item < nitem ? min((c + 1) * kChunk, count) : l0[j];
+            // a code that is never met at the level of the chunk's first leaf stays poison
+            if (!((rv >> 14) & (1u << ((first + l0[j]) & 1ull)))) l1[j] = l0[j], st[j] = SNB + 2;
         }
+        uint32_t at[kIlp];              // leaf (relative to l0) in front of which the chain got stuck
+#pragma unroll
+        for (int j = 0; j < kIlp; ++j) at[j] = kChunk;
         for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
 #pragma unroll
             for (int j = 0; j < kIlp; ++j) {
                 const uint32_t l = l0[j] + step;
-                if (l < l1[j]) st[j] = leaf_step(b.tab, rep, skip, D, SNB, l, st[j]);
+                if (l < l1[j]) {
+                    // branch-free on the state (stuck codes wait like poison): the kIlp chains must stay interleaved
+                    const uint32_t v = st[j];
+                    const uint32_t a = b.tab[(uint32_t)rep[l] * SNB + (v < SNB ? v : 0u)];
+                    const uint32_t k = skip[l][v == SNB + 1 ? 1 : 0];
+                    const uint32_t nv = v < SNB ? a : (v < SNB + 2 ? k : v);
+                    at[j] = (nv > SNB + 2 && v <= SNB + 2) ? step + 1 : at[j];
+                    st[j] = nv;
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
             const uint32_t item = base + j * blockDim.x;
-            if (item < nitem) b.ctab[dst[j]] = (uint16_t)st[j];
+            if (item >= nitem) continue;
+            if (st[j] > SNB + 2) {
+                for (uint32_t l = l0[j] + at[j]; l < l1[j]; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
+            }
+            b.ctab[dst[j]] = (uint16_t)st[j];
+        }
+    }
+    // chains that START in a stuck code: only behind a leaf that can end stuck -- nowhere in
+    // a clean capture
+    bool any = false;
+    for (uint32_t w = 0; w < kCapWords; ++w) any = any || cap[w] != 0;
+    if (any && T.NS) {
+        const uint32_t nst = T.NS * T.depth;
+        for (uint32_t item = threadIdx.x; item < nch * nst; item += blockDim.x) {
+            const uint32_t c = item / nst, code = D0 + (item - c * nst);
+            const uint32_t la = c * kChunk, lb = min((c + 1) * kChunk, count);
+            // STUCK_d enters the chunk only if the leaf d before it can end stuck
+            const uint32_t ob = la + kStuckDepth - ((code - D0) / T.NS + 1);
+            if (!(cap[ob >> 5] & (1u << (ob & 31u)))) continue;
+            uint32_t v = code;
+            for (uint32_t l = la; l < lb; ++l) v = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, v);
+            b.ctab[c * D + code] = (uint16_t)v;
         }
     }
     __syncthreads();
@@ -980,11 +1153,29 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
     __shared__ uint16_t s_skip[256][2];
+    __shared__ uint32_t s_cap[kCapWords];
+    __shared__ uint32_t s_lt[kLtLdsWords];
     copy_ltab(T, sp.ltab);
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
-    const BlockLds b = carve(LB, D);
+    const BlockLds b = carve(LB, D, T.S * T.NB1);
+    // the span tables (a few hundred words for the shipped devices) are searched from LDS
+    const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
+    if (lt_off) {
+        const uint32_t noff = 2 * (2 * T.S + 2) + 1, nint = lt_off[noff - 1];
+        if (noff + 2 * nint <= kLtLdsWords) {
+            for (uint32_t i = threadIdx.x; i < noff; i += blockDim.x) s_lt[i] = sp.lt_off[i];
+            for (uint32_t i = threadIdx.x; i < nint; i += blockDim.x) {
+                s_lt[noff + i] = sp.lt_n0[i];
+                s_lt[noff + nint + i] = sp.lt_pk[i];
+            }
+            lt_off = s_lt;
+            lt_n0 = s_lt + noff;
+            lt_pk = s_lt + noff + nint;
+            __syncthreads();
+        }
+    }
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     for (uint32_t gb = blockIdx.x; gb < total + sp.f.num_captures; gb += gridDim.x) {
         if (gb >= total) {
@@ -1010,7 +1201,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const uint64_t st0 = __builtin_amdgcn_s_memtime();
-        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq, sp.lt_off, sp.lt_n0, sp.lt_pk,
+        const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
+        block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq, lt_off, lt_n0, lt_pk, s_cap,
                    (sp.f.debug && gb == 2) ? sp.f.debug + 40 : nullptr);
         const uint64_t st1 = __builtin_amdgcn_s_memtime();
         {
@@ -1019,15 +1211,15 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
             for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
         }
-        block_expand(T, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
+        block_expand(T, sc, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        compose_chunks(b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach);
+        compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach_base);
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;
             sp.f.debug[4 * gb + 1] = st2 - st1;
             sp.f.debug[4 * gb + 2] = st3 - st2;
-            sp.f.debug[4 * gb + 3] = s_uniq[0];
+            sp.f.debug[4 * gb + 3] = s_uniq[0] | ((uint64_t)(s_cap[0] | s_cap[1] | s_cap[2]) << 32);
         }
         // the block's table: every abstract state walks the chunk tables (kept for emit)
         const uint32_t nch = (count + kChunk - 1) / kChunk;
@@ -1074,7 +1266,7 @@ __global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     if (*sp.fallback) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kGroup][Dp]
-    const uint32_t D = sp.f.tables->num_states * (sp.f.tables->max_bits + 2) + 3;
+    const uint32_t D = sp.D;            // the whole domain, stuck codes included
     const uint32_t total = sp.cap_group_off[sp.f.num_captures];
     for (uint32_t gg = blockIdx.x; gg < total; gg += gridDim.x) {
         uint32_t cap, lg;
@@ -1135,7 +1327,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
-    const BlockLds b = carve(LB, D);
+    const BlockLds b = carve(LB, D, T.S * T.NB1);
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     // work items: every block, then one "ends" item per capture (first span + tail)
     for (uint32_t w = blockIdx.x; w < total + sp.f.num_captures; w += gridDim.x) {
@@ -1148,6 +1340,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             LeafEvDev *events = sp.events + e0 + cap;
             const uint64_t first = 1 + (uint64_t)lb * LB;
             const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+            const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
             {
                 const uint32_t nsim = 2 * T.S + 2;
                 const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
@@ -1188,7 +1381,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 uint32_t s = cin[c];
                 for (uint32_t l = c * kChunk; l < l1; ++l) {
                     pre[l] = (uint16_t)s;
-                    s = leaf_step_packed(T, edges, first, l, b.res, s_resume, s);
+                    s = leaf_step_packed(T, sc, edges, first, l, b.res, s_resume, s);
                 }
             }
             __syncthreads();
@@ -1197,7 +1390,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
             for (uint32_t l = threadIdx.x & 63u; l < count; l += 64) {
                 const uint64_t i = first + l;
-                const uint32_t in = pre[l];
+                uint32_t in = pre[l];
                 if ((in / T.NB1) % nwaves != wave) continue;
                 PSim f;
                 Acc a;
@@ -1207,7 +1400,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     acc_init(a);
                     f.cur = f.nbits = f.k = f.prev = 0;
                 } else {
-                    alive = run_leaf(T, in, span_of(edges, i), s_resume[l], f, a);
+                    const Span span = span_entered(T, edges, i, in);       // stuck: from where it was normal
+                    alive = run_leaf(T, in, span, s_resume[l], f, a);
                     if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
                 }
                 write_event(events[i], a, f, alive);
@@ -1240,10 +1434,21 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 }
                 const uint64_t pos0 = edges[ne - 1] + 1;
                 Span tail;
+                tail.prefix = 0;
                 tail.pos0 = pos0;
                 tail.n = sp.f.n_out > pos0 ? sp.f.n_out - pos0 : 0;
                 tail.L = (uint32_t)(ne & 1ull);
                 tail.has_edge = false;
+                if (in > code_poison(T)) {              // entered stuck: run it from where the state was normal
+                    uint32_t d, src;
+                    stuck_decode(T, in, d, src);
+                    if (ne >= (uint64_t)d + 1) {
+                        tail.prefix = edges[ne - 1] - edges[ne - d - 1];
+                        in = src;
+                    } else {
+                        in = code_poison(T);
+                    }
+                }
                 PSim f;
                 Acc a;
                 bool alive = true;
@@ -1639,6 +1844,22 @@ void fill_ltab_host(LTab &T, const FsmTablesDev &g, uint32_t spb, uint32_t decim
     T.D = g.num_states * (g.max_bits + 2) + 3;
     T.spb = spb;
     T.decim = decim;
+    T.NS = 0;
+    T.nstuck_rows = 0;
+    T.depth = 0;
+}
+
+// adds the stuck codes (found by build_leaf_tables) to the domain
+void add_stuck(LTab &T, const std::vector<uint16_t> &stuck_src, const std::vector<uint8_t> &stuck_rows) {
+    if (stuck_src.empty() || stuck_src.size() > kMaxStuck || stuck_rows.size() > kMaxStuckRows) return;
+    const uint32_t room = T.D < kStuckDomain ? (kStuckDomain - T.D) / (uint32_t)stuck_src.size() : 0u;
+    if (room == 0) return;                              // no room in the domain: they stay poison
+    T.depth = room < kStuckDepth ? room : kStuckDepth;
+    T.NS = (uint32_t)stuck_src.size();
+    T.nstuck_rows = (uint32_t)stuck_rows.size();
+    for (size_t i = 0; i < stuck_src.size(); ++i) T.stuck_src[i] = stuck_src[i];
+    for (size_t i = 0; i < stuck_rows.size(); ++i) T.stuck_row[i] = stuck_rows[i];
+    T.D += T.NS * T.depth;
 }
 
 constexpr uint64_t kProbePos = 1ull << 40;      // spans of normal rows do not depend on where they lie
@@ -1719,72 +1940,114 @@ void row_candidates(const LTab &T, PSim f, uint32_t L, bool first_is_edge, std::
 
 size_t fsm_scan_ltab_bytes() { return sizeof(LTab); }
 
-void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &g, uint32_t spb, uint32_t decim) {
+uint32_t fsm_scan_fill_ltab(void *dst, const FsmTablesDev &g, uint32_t spb, uint32_t decim,
+                            const std::vector<uint16_t> &stuck_src, const std::vector<uint8_t> &stuck_rows) {
     memset(dst, 0, sizeof(LTab));
-    fill_ltab_host(*static_cast<LTab *>(dst), g, spb, decim);
+    LTab &T = *static_cast<LTab *>(dst);
+    fill_ltab_host(T, g, spb, decim);
+    add_stuck(T, stuck_src, stuck_rows);
+    return T.D;
 }
 
-// Abstract codes a span can be entered in: closure of {reset, skip x2, poison} under every
-// result the span tables hold (any length, either level).  Entries that need a
-// simulation add nothing: they are spans with an error before their last sample, which
-// end either skipping or as a run from (reset, no bits) at a buffer start with the
-// previous level equal to the span's -- a result of row (reset, few bits) again.
-// Empty = unknown (a bit-count sensitive result): the kernels then compose over all
+// Abstract codes a span can be entered in, and with which level: closure of {reset at
+// level 0, skip x2, poison} under every result the span tables hold (any length).  Entries
+// that need a simulation add nothing: they are spans with an error before their last
+// sample, which end either skipping or as a run from (reset, no bits) at a buffer start
+// with the previous level equal to the span's -- a result of row (reset, few bits) again.
+// A normal code whose (row, level) holds a "stuck" result while it is reachable at that
+// level joins stuck_src: those codes get STUCK_1..kStuckDepth twins in the domain (results
+// of a stuck code are results of its row again, at either level).
+// reach empty = unknown (a bit-count sensitive result): the kernels then compose over all
 // codes.  (A code missed here would only cost speed: its entries are poison, and a
 // poisoned capture falls back to the rounds.)
-static void reachable_codes(const LTab &T, const std::vector<uint32_t> &off, const std::vector<uint32_t> &pk,
-                            std::vector<uint16_t> &reach) {
-    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D;
-    std::vector<char> in(D, 0);
+static void reachable_codes(LTab &T, const std::vector<uint32_t> &off, const std::vector<uint32_t> &pk,
+                            std::vector<uint16_t> &reach, std::vector<uint16_t> &stuck_src,
+                            std::vector<uint8_t> &stuck_rows) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D0 = SNB + 3;
+    std::vector<char> in(2 * D0, 0), stuck(SNB, 0);
     std::vector<uint32_t> todo;
-    auto add = [&](uint32_t code) {
-        if (code < D && !in[code]) {
-            in[code] = 1;
-            todo.push_back(code);
+    bool unknown = false;
+    auto add = [&](uint32_t code, uint32_t L) {
+        if (code < D0 && !in[2 * code + L]) {
+            in[2 * code + L] = 1;
+            todo.push_back(2 * code + L);
         }
     };
-    // results of table (row, L) entered with nb bits; false = unknown
-    auto follow = [&](uint32_t row, uint32_t nb) {
-        for (uint32_t L = 0; L < 2; ++L) {
-            for (uint32_t i = off[2 * row + L]; i < off[2 * row + L + 1]; ++i) {
-                const uint32_t v = pk[i];
-                if (v & kPkAbsolute) {
-                    add(v & 0xffffu);
-                } else if (v & kPkRelative) {
-                    const uint32_t nbo = nb + ((v >> 8) & 0xffffu);
-                    add((v & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo));
-                } else if (v & kPkSensitive) {
-                    return false;
-                }
+    // results of table (row, L) entered with nb bits; they are entered at level `next`
+    auto follow = [&](uint32_t row, uint32_t L, uint32_t nb, uint32_t next) -> bool {
+        bool any_stuck = false;
+        for (uint32_t i = off[2 * row + L]; i < off[2 * row + L + 1]; ++i) {
+            const uint32_t v = pk[i];
+            uint32_t c = D0;
+            if (v & kPkAbsolute) {
+                c = v & 0xffffu;
+            } else if (v & kPkRelative) {
+                const uint32_t nbo = nb + ((v >> 8) & 0xffffu);
+                c = (v & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+            } else if (v & kPkSensitive) {
+                unknown = true;
+            } else if (v & kPkStuck) {
+                any_stuck = true;
             }
+            if (c < D0) add(c, next);
         }
-        return true;
+        return any_stuck;
     };
     reach.clear();
-    add(0);
-    add(SNB);
-    add(SNB + 1);
-    add(SNB + 2);
-    while (!todo.empty()) {
-        const uint32_t code = todo.back();
+    stuck_src.clear();
+    stuck_rows.clear();
+    add(0, 0);                                          // a capture starts in reset, at level 0
+    for (uint32_t L = 0; L < 2; ++L) {
+        add(SNB, L);
+        add(SNB + 1, L);
+        add(SNB + 2, L);
+    }
+    while (!todo.empty() && !unknown) {
+        const uint32_t code = todo.back() >> 1, L = todo.back() & 1u;
         todo.pop_back();
         if (code == SNB + 2) continue;
-        bool known;
         if (code >= SNB) {
-            known = follow(2 * S + (code - SNB), 0u);           // skipping ends inside a span of the other level
-        } else {
-            const uint32_t cur = code / NB1, nb = code - cur * NB1;
-            known = follow(2 * cur + (nb >= T.max_bits ? 1u : 0u), nb);
+            const uint32_t kk = code - SNB;             // skipping ends inside the span, or goes on
+            follow(kk == L ? 0u : 2 * S + kk, L, 0u, L ^ 1u);
+            add(code, L ^ 1u);
+            continue;
         }
-        if (!known) return;
+        const uint32_t cur = code / NB1, nb = code - cur * NB1;
+        const uint32_t row = 2 * cur + (nb >= T.max_bits ? 1u : 0u);
+        if (follow(row, L, nb, L ^ 1u)) {
+            stuck[code] = 1;
+            const uint8_t rl = (uint8_t)(row | (L << 7));
+            if (row < 128 && std::find(stuck_rows.begin(), stuck_rows.end(), rl) == stuck_rows.end()) stuck_rows.push_back(rl);
+            follow(row, 0, nb, 1);                      // what its stuck twins can end in
+            follow(row, 1, nb, 0);
+        }
     }
-    for (uint32_t c = 0; c < D; ++c) {
-        if (in[c]) reach.push_back((uint16_t)c);
+    if (getenv("OOKD_DEBUG_REACH")) {
+        size_t ns = 0, nr = 0;
+        for (char c : stuck) ns += c;
+        for (char c : in) nr += c;
+        fprintf(stderr, "[reach] unknown %d stuck %zu in %zu todo %zu\n", (int)unknown, ns, nr, todo.size());
     }
+    if (unknown) return;
+    for (uint32_t c = 0; c < SNB; ++c) {
+        if (!stuck[c]) continue;
+        stuck_src.push_back((uint16_t)c);
+    }
+    add_stuck(T, stuck_src, stuck_rows);
+    if (!T.NS) {
+        stuck_src.clear();                              // too many: they stay unrepresentable (poison)
+        stuck_rows.clear();
+    }
+    // entry = code | levels it is met at << 14 (bit 14: level 0, bit 15: level 1)
+    for (uint32_t c = 0; c < D0; ++c) {
+        if (in[2 * c] || in[2 * c + 1]) reach.push_back((uint16_t)(c | (in[2 * c] ? 0x4000u : 0u) | (in[2 * c + 1] ? 0x8000u : 0u)));
+    }
+    for (uint32_t c = D0; c < T.D; ++c) reach.push_back((uint16_t)(c | 0xc000u));
 }
 
 bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
-                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach) {
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach,
+                       std::vector<uint16_t> &stuck_src, std::vector<uint8_t> &stuck_rows) {
     std::unique_ptr<LTab> Tp(new LTab());
     LTab &T = *Tp;
     fill_ltab_host(T, g, spb, decim);
@@ -1844,7 +2107,7 @@ bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std:
         }
     }
     off[2 * rows] = (uint32_t)n0.size();
-    reachable_codes(T, off, pk, reach);
+    reachable_codes(T, off, pk, reach, stuck_src, stuck_rows);
     return true;
 }
 
@@ -1852,11 +2115,11 @@ bool build_leaf_tables(const FsmTablesDev &g, uint32_t spb, uint32_t decim, std:
 // launcher
 // ---------------------------------------------------------------------------
 
-uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S) {
+uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB) {
     // 64 leaves per block: about one simulation task per lane, and the tables
     // (~35 KiB for the shipped devices) let several workgroups share a CU
     uint32_t lb = 64;
-    while (lb > 16 && block_lds_bytes(lb, D, S) > 140u * 1024u) lb >>= 1;
+    while (lb > 16 && block_lds_bytes(lb, D, S, SNB) > 140u * 1024u) lb >>= 1;
     return lb;
 }
 
@@ -1892,13 +2155,15 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     // with a concrete incoming state (shards) the first span may leave the closure: no pruning
     sp.reach = a.first ? nullptr : a.reach;
     sp.nreach = a.first ? 0 : a.nreach;
+    sp.nreach_base = a.first ? 0 : a.nreach_base;
     sp.Dp = (a.D + 7u) & ~7u;
+    sp.D = a.D;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;
     sp.group_in = a.group_in;
     sp.cap_end = a.cap_end;
     sp.cap_first = a.cap_first;
-    const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S);
+    const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S, a.SNB);
     const size_t lds_group = (size_t)kGroup * sp.Dp * 2;
     const size_t lds_walk = (size_t)128 * sp.Dp * 2;
     if (lds_walk > 150u * 1024u) return hipErrorInvalidValue;

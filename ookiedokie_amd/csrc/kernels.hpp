@@ -214,7 +214,8 @@ static_assert(sizeof(LeafEvDev) == 48, "LeafEvDev layout");
 
 struct FsmScanArgs {
     FsmParams f;                // tables, edges, geometry, msgs / totals
-    uint32_t D, S;              // abstract states, machine states
+    uint32_t D, S;              // abstract states (with stuck codes), machine states
+    uint32_t SNB;               // S * (max_bits + 2): the normal codes
     uint32_t leaf_block;        // from fsm_scan_leaf_block()
     uint32_t grid_blocks;       // persistent workgroups for the leaf / emit kernels
     uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
@@ -223,8 +224,8 @@ struct FsmScanArgs {
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
     PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
-    const uint16_t *reach;      // codes a span can be entered in, or null = all
-    uint32_t nreach;
+    const uint16_t *reach;      // codes a span can be entered in (ascending), or null = all
+    uint32_t nreach, nreach_base;       // all / those below the stuck codes (S * (max_bits + 2) + 3)
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]
@@ -247,17 +248,21 @@ struct FsmScanArgs {
     uint16_t *cap_first;        // [captures]
 };
 
-uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S);
+uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB);
 // The trigger / state tables in the layout the scan kernels keep in LDS: size, and
 // a host-side fill (16-byte aligned destination) to be uploaded once per context.
 size_t fsm_scan_ltab_bytes();
-void fsm_scan_fill_ltab(void *dst, const FsmTablesDev &tables, uint32_t spb, uint32_t decim);
+// returns the size of the abstract domain (states x bit counts + 3 + stuck codes)
+uint32_t fsm_scan_fill_ltab(void *dst, const FsmTablesDev &tables, uint32_t spb, uint32_t decim,
+                            const std::vector<uint16_t> &stuck_src, const std::vector<uint8_t> &stuck_rows);
 // Packed result of a span as a step function of its length, per (row, level)
 // (host side; false = not tabulated, the kernels simulate).
 // reach: the abstract codes a span can be entered in (closure of the tables' results);
-// empty when that cannot be told.
+// empty when that cannot be told.  stuck_src / stuck_rows: the normal codes / table rows with
+// a "no trigger fired on the edge" result (they extend the domain: fsm_scan_fill_ltab).
 bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
-                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach);
+                       std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach,
+                       std::vector<uint16_t> &stuck_src, std::vector<uint8_t> &stuck_rows);
 uint32_t fsm_scan_fin_block();
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
 

@@ -296,6 +296,7 @@ struct ookd_rx {
     bool scan_pending = false;      // a scan is queued; its verdict is read with the results
     bool pending_first_valid = false;
     FsmStateDev pending_first{};
+    uint32_t scan_reach_base = 0;   // reach entries below the stuck codes
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab, d_chunk_tab;
@@ -616,6 +617,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.f = fsm_params();
     a.D = scan_D;
     a.S = scan_S;
+    a.SNB = scan_S * (scan_max_bits + 2);
     a.leaf_block = scan_leaf_block;
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
@@ -626,6 +628,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.ltab = d_ltab.p;
     a.reach = d_reach.p;
     a.nreach = (uint32_t)d_reach.n;
+    a.nreach_base = scan_reach_base;
     a.publish = publish_params();
     a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
@@ -662,9 +665,10 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
                 (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
                 (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
         for (int i = 0; i < 4; ++i)
-            fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans\n", i,
+            fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans, cap %llx\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
-                    (unsigned long long)dbg[4 * i + 2], (unsigned long long)dbg[4 * i + 3]);
+                    (unsigned long long)dbg[4 * i + 2], (unsigned long long)(dbg[4 * i + 3] & 0xffffffffu),
+                    (unsigned long long)(dbg[4 * i + 3] >> 32));
     }
     if (debug_scan && debug_scan[0] == '2') {
         uint32_t off[2];
@@ -676,7 +680,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
         fprintf(stderr, "[scan] blocks %u..%u ne %u D %u LB %u\n", off[0], off[1], ne, scan_D, scan_leaf_block);
         std::vector<LeafEvDev> evs(ne + 1);
         HIPCHK(hipMemcpy(evs.data(), d_events.p, (ne + 1) * sizeof(LeafEvDev), hipMemcpyDeviceToHost));
-        for (uint32_t i = ne > 6 ? ne - 6 : 0; i <= ne; ++i)
+        for (uint32_t i = 0; i <= ne && i < 14; ++i)
             fprintf(stderr, "[scan] leaf %u napp %u nout %u nerr %u flags %u end cur %u k %u prev %u\n", i,
                     evs[i].napp, evs[i].nout, evs[i].nerr, evs[i].flags, evs[i].end_cur, evs[i].end_k, evs[i].end_prev);
     }
@@ -991,18 +995,25 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rx->scan_max_bits = device->num_bits;
         rx->scan_D = rx->scan_S * (device->num_bits + 2) + 3;
         rx->scan_ok = !(cfg->flags & OOKD_RX_FSM_ROUNDS) && rx->scan_D <= 384 && device->num_bits <= 254;
+        std::vector<uint16_t> stuck_src;        // normal codes an inert edge can leave stuck (domain extension)
+        std::vector<uint8_t> stuck_rows;
         if (rx->scan_ok && !(cfg->flags & OOKD_RX_SCAN_SIMS)) {
             // span tables: packed result of a span as a step function of its length
             std::vector<uint32_t> off, n0, pk;
             std::vector<uint16_t> reach;
             const auto t0 = std::chrono::steady_clock::now();
             const bool ok = build_leaf_tables(*rx->h_tables, cfg->samples_per_buffer, rx->total_decim, off, n0, pk,
-                                              reach);
+                                              reach, stuck_src, stuck_rows);
+            if (!ok) {
+                stuck_src.clear();
+                stuck_rows.clear();
+            }
             if (getenv("OOKD_DEBUG")) {
                 size_t zeros = 0;
                 for (uint32_t v : pk) zeros += v == 0;
-                fprintf(stderr, "[ookd] span tables: %s, %zu intervals (%zu need simulation), %zu of %u codes reachable, %.1f ms\n",
-                        ok ? "built" : "REFUSED", n0.size(), zeros, reach.size(), rx->scan_D,
+                fprintf(stderr, "[ookd] span tables: %s, %zu intervals (%zu need simulation), %zu codes can get stuck, "
+                                "%zu codes reachable, %.1f ms\n",
+                        ok ? "built" : "REFUSED", n0.size(), zeros, stuck_src.size(), reach.size(),
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 if (getenv("OOKD_DEBUG")[0] == '2') {
                     for (size_t t = 0; t + 1 < off.size(); ++t) {
@@ -1013,6 +1024,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 }
             }
             if (ok && !reach.empty()) {
+                const uint32_t d0 = rx->scan_S * (device->num_bits + 2) + 3;
+                rx->scan_reach_base = 0;                // entries are code | level mask << 14, ascending in the code
+                for (uint16_t v : reach) rx->scan_reach_base += (v & 0x3fffu) < d0 ? 1u : 0u;
                 rc |= rx->d_reach.alloc(reach.size());
                 if (rc == OOKD_OK && hipMemcpy(rx->d_reach.p, reach.data(), reach.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
                     rc = OOKD_ERR_HIP;
@@ -1032,13 +1046,14 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         }
         if (rx->scan_ok) {
             std::vector<uint4> image((fsm_scan_ltab_bytes() + 15) / 16);
-            fsm_scan_fill_ltab(image.data(), *rx->h_tables, cfg->samples_per_buffer, rx->total_decim);
+            rx->scan_D = fsm_scan_fill_ltab(image.data(), *rx->h_tables, cfg->samples_per_buffer, rx->total_decim,
+                                            stuck_src, stuck_rows);
             rc |= rx->d_ltab.alloc(image.size());
             if (rc == OOKD_OK &&
                 hipMemcpy(rx->d_ltab.p, image.data(), image.size() * 16, hipMemcpyHostToDevice) != hipSuccess) {
                 rc = OOKD_ERR_HIP;
             }
-            rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S);
+            rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S, rx->scan_S * (rx->scan_max_bits + 2));
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
             rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
             rc |= rx->d_chunk_tab.alloc((size_t)rx->scan_blocks_cap * (rx->scan_leaf_block / 16) * ((rx->scan_D + 7u) & ~7u) + 64);
@@ -1171,6 +1186,40 @@ int ookd_rx_process_host(ookd_rx *rx, const int16_t *iq, uint64_t num_samples) {
 }
 
 uint64_t ookd_rx_halo_samples(const ookd_rx *rx) { return rx ? rx->halo_needed : 0; }
+
+int ookd_scan_domain_info(const ookd_device *device, uint32_t samples_per_buffer, uint32_t total_decimation,
+                          uint32_t out[8]) {
+    clear_error();
+    if (!device || !out || !samples_per_buffer || !total_decimation) {
+        set_error("ookd_scan_domain_info: bad argument");
+        return OOKD_ERR_ARG;
+    }
+    std::unique_ptr<FsmTablesDev> t(new FsmTablesDev());
+    memset(t.get(), 0, sizeof(FsmTablesDev));
+    fill_fsm_tables(*device, *t);
+    std::vector<uint32_t> off, n0, pk;
+    std::vector<uint16_t> reach, stuck_src;
+    std::vector<uint8_t> stuck_rows;
+    const bool ok = build_leaf_tables(*t, samples_per_buffer, total_decimation, off, n0, pk, reach, stuck_src,
+                                      stuck_rows);
+    size_t zeros = 0;
+    for (uint32_t v : pk) zeros += v == 0;
+    const uint32_t S = (uint32_t)device->state_duration_us.size();
+    out[0] = ok ? 1u : 0u;
+    out[1] = (uint32_t)n0.size();
+    out[2] = (uint32_t)zeros;
+    out[3] = (uint32_t)reach.size();
+    out[4] = ok ? (uint32_t)stuck_src.size() : 0u;
+    out[5] = ok ? (uint32_t)stuck_rows.size() : 0u;
+    std::vector<uint4> image((fsm_scan_ltab_bytes() + 15) / 16);
+    if (!ok) {
+        stuck_src.clear();
+        stuck_rows.clear();
+    }
+    out[6] = fsm_scan_fill_ltab(image.data(), *t, samples_per_buffer, total_decimation, stuck_src, stuck_rows);
+    out[7] = S;
+    return OOKD_OK;
+}
 
 int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, const int16_t *halo,
                         uint64_t halo_samples, int last_shard, const ookd_fsm_state *state_in,

@@ -407,6 +407,49 @@ def test_g7_tolerance_boundaries(ok, oracle, vectors):
             rx.close()
 
 
+@pytest.mark.parametrize("devname", ["p3l-nexa2012", "unknown-remote1"])
+def test_glitches_inside_bit_gaps_stay_in_the_scan(ok, oracle, devname):
+    """A short pulse inside a bit gap: no trigger fires on its two edges (bit_off_time
+    has no window for them), the counter runs on and the next real edge is judged by the
+    whole gap -- the reference decodes the message as if nothing had happened.  The scan
+    form holds such stretches as "stuck" codes; with 70 messages and the glitch at a
+    different bit each time the stretches cross chunk (16 leaves), block (64) and group
+    (1024) boundaries.  Must not fall back, must equal the oracle."""
+    sh = {"p3l-nexa2012": dict(bits=36, start=500, first=8700, pulse=500, gap0=2000, gap1=4000),
+          "unknown-remote1": dict(bits=32, start=8900, first=4400, pulse=550, gap0=550, gap1=1700)}[devname]
+    rng = np.random.default_rng(77)
+    us = RATE // 1000000
+    runs = [5000]
+    for m in range(70):
+        runs += [sh["start"] * us, sh["first"] * us]
+        bits = rng.integers(0, 2, size=sh["bits"])
+        hit = {int(x) for x in rng.choice(sh["bits"], size=1 + m % 3, replace=False)}
+        for i, bit in enumerate(bits):
+            gap = (sh["gap1"] if bit else sh["gap0"]) * us
+            runs.append(sh["pulse"] * us)
+            if i in hit and gap > 900:
+                a = int(rng.integers(100, min(gap - 700, 900)))     # ends before any bit window opens
+                g = int(rng.integers(20, 400))
+                runs += [a, g, gap - a - g]          # gap = a + glitch + rest: the rising edge still sees `gap`
+            else:
+                runs.append(gap)
+        runs += [sh["pulse"] * us, int(rng.integers(12000, 40000))]
+    iq = _iq_from_stream(stream_from_runs(runs))
+    d = _dev(ok, devname)
+    od = _odev(oracle, devname)
+    want = oracle.rx(iq, None, 0.1, od, 8192)
+    assert len(want.msg_samples) >= 60          # the glitches do not break the messages
+    for spb in (8192, 1000):
+        want = oracle.rx(iq, None, 0.1, od, spb)
+        rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=spb)
+        got = rx.rx(iq)
+        assert got.stats["fsm_path"] == 1, got.stats["fsm_fallback_reason"]
+        assert list(got.msg_samples) == list(want.msg_samples)
+        assert (got.payloads == want.payloads).all()
+        assert got.stats["num_errors"] == len(want.err_samples)
+        rx.close()
+
+
 @pytest.mark.parametrize("segment_buffers", [1, 3, 0, -1])
 def test_reference_fsm_fixtures_random_streams(ok, oracle, vectors, segment_buffers):
     # segment_buffers >= 0: the round path with that segment size; -1: the scan path

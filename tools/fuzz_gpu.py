@@ -41,6 +41,20 @@ def jitter(rng, us, rate, mode):
     return max(1, int(round(n * f)))
 
 
+def glitched(rng, runs, rate):
+    """Short pulses inside low runs (every other run, starting with the second): the edges of
+    such a pulse usually fire nothing -- the state machine's counter runs on."""
+    out = []
+    for i, r in enumerate(runs):
+        if i % 2 == 1 and r > 40 and rng.random() < 0.15:
+            a = int(rng.integers(1, r - 2))
+            g = int(rng.integers(1, min(r - a, max(2, int(400 * rate / 3e6)))))
+            out += [a, g, max(1, r - a - g)]
+        else:
+            out.append(r)
+    return out
+
+
 def message_runs(rng, shape, rate):
     p_bad = rng.choice([0.0, 0.02, 0.1])
     def j(us):
@@ -57,10 +71,12 @@ def message_runs(rng, shape, rate):
 
 def capture_runs(rng, shape, rate):
     runs = [int(rng.integers(1, 20000))]         # leading off time
-    for _ in range(int(rng.integers(1, 7))):
+    many = rate <= 1000000 and rng.random() < 0.3      # now and then a long capture: > 1024 edges
+    for _ in range(int(rng.integers(20, 45)) if many else int(rng.integers(1, 7))):
         if rng.random() < 0.3:                   # glitch pulse before the message
             runs += [max(1, int(rng.integers(1, 400) * rate / 3e6)), max(1, int(rng.integers(100, 9000) * rate / 3e6))]
-        runs += message_runs(rng, shape, rate)
+        msg = message_runs(rng, shape, rate)
+        runs += glitched(rng, msg, rate) if rng.random() < 0.5 else msg
         gap_us = rng.choice([300, 1000, 4000, 12000, 20000]) * rng.uniform(0.8, 1.3)
         runs += [max(1, int(gap_us * rate / 1e6))]
     return runs
