@@ -589,9 +589,13 @@ __device__ __forceinline__ uint32_t stuck_enter(const LTab &T, const StuckCtx &c
 }
 
 __device__ __forceinline__ void stuck_decode(const LTab &T, uint32_t code, uint32_t &d, uint32_t &src) {
-    const uint32_t rel = code - (T.S * T.NB1 + 3);
-    d = rel / T.NS + 1;
-    src = T.stuck_src[rel - (d - 1) * T.NS];
+    uint32_t rel = code - (T.S * T.NB1 + 3);
+    d = 1;
+    while (rel >= T.NS && d < kStuckDepth) {            // d <= kStuckDepth: cheaper than a division
+        rel -= T.NS;
+        ++d;
+    }
+    src = T.stuck_src[rel < T.NS ? rel : 0u];
 }
 
 // Leaf i (edge index in the capture) entered in a stuck code: no trigger fired on the d

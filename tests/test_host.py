@@ -190,6 +190,26 @@ def test_synth_tx_walk_matches_reference_sm_generate(oracle):
         assert syn.message(0)[0] == int(4000 * rate / 1e6 + 0.5)
 
 
+@pytest.mark.parametrize("name,stuck", [("p3l-nexa2012", 36), ("unknown-remote1", 32)])
+@pytest.mark.parametrize("rate", [3000000, 750000])
+def test_scan_domain_of_the_shipped_devices(name, stuck, rate):
+    """Host logic of the scan form (no GPU): span tables build, every interval is a
+    looked-up result, the level-aware closure finds the codes a glitch inside a bit gap
+    leaves "stuck" (bit_off_time with fewer than max_bits bits, one table row), and the
+    domain with their twins stays within 384 codes."""
+    d = ok.Device.load(golden_path("devices", name), rate)
+    out = (C.c_uint32 * 8)()
+    assert ok.lib().ookd_scan_domain_info(d._h, 8192, 1, out) == 0
+    built, intervals, need_sim, reach, nstuck, stuck_rows, domain, states = list(out)
+    assert built == 1 and need_sim == 0 and states == 6
+    assert intervals == 74
+    assert nstuck == stuck and stuck_rows == 1
+    base = states * (d.num_bits + 2) + 3
+    depth = (domain - base) // nstuck
+    assert domain == base + depth * nstuck and 3 <= depth <= 8 and domain <= 384
+    assert base // 3 < reach <= domain          # far fewer than all codes are ever entered
+
+
 def test_synth_is_deterministic_and_windowed():
     dev = ok.Device.load(golden_path("devices", "unknown-remote1"), 3000000)
     a = ok.Synth(dev, 500_000, seed=3).fill_host()
