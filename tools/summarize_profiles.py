@@ -23,7 +23,9 @@ ALGO_BYTES = 4.125 * (1 << 28)
 
 def counter_avg(dirname, counter):
     vals = []
-    for f in glob.glob(os.path.join(dirname, "*", "*counter_collection.csv")):
+    # gpurun_out/ accumulates the files of earlier collections: only the newest one counts
+    files = sorted(glob.glob(os.path.join(dirname, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) > (1 << 22):
@@ -35,9 +37,9 @@ def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + rnd)
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, rnd + "_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(dst, rnd + "_kernel_stats.csv"))
     fetch, nf = counter_avg(os.path.join(src, "fetch"), "FETCH_SIZE")
     write, nw = counter_avg(os.path.join(src, "write"), "WRITE_SIZE")
     if fetch is not None and write is not None:
