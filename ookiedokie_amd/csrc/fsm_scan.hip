@@ -56,7 +56,7 @@ constexpr int kScanThreads = 1024;
 // goes on: STUCK_d(s) = "entered d leaves ago in normal state s, no trigger fired on the
 // d edges since" -- the next leaf is row(s) evaluated at the merged length.
 constexpr uint32_t kStuckDepth = 8;     // inert edges in a row that stay representable, at most (LTab.depth)
-constexpr uint32_t kStuckDomain = 384;  // the stuck codes may grow the domain up to this size
+constexpr uint32_t kStuckDomain = 512;  // the stuck codes may grow the domain up to this size
 constexpr uint32_t kMaxStuck = 256;     // normal codes that can get stuck (p3l-nexa2012: 37)
 constexpr uint32_t kMaxStuckRows = 32;
 

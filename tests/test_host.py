@@ -196,7 +196,7 @@ def test_scan_domain_of_the_shipped_devices(name, stuck, rate):
     """Host logic of the scan form (no GPU): span tables build, every interval is a
     looked-up result, the level-aware closure finds the codes a glitch inside a bit gap
     leaves "stuck" (bit_off_time with fewer than max_bits bits, one table row), and the
-    domain with their twins stays within 384 codes."""
+    domain with their twins stays within 512 codes."""
     d = ok.Device.load(golden_path("devices", name), rate)
     out = (C.c_uint32 * 8)()
     assert ok.lib().ookd_scan_domain_info(d._h, 8192, 1, out) == 0
@@ -206,7 +206,7 @@ def test_scan_domain_of_the_shipped_devices(name, stuck, rate):
     assert nstuck == stuck and stuck_rows == 1
     base = states * (d.num_bits + 2) + 3
     depth = (domain - base) // nstuck
-    assert domain == base + depth * nstuck and 3 <= depth <= 8 and domain <= 384
+    assert domain == base + depth * nstuck and 3 <= depth <= 8 and domain <= 512
     assert base // 3 < reach <= domain          # far fewer than all codes are ever entered
 
 
