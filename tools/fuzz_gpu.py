@@ -90,8 +90,71 @@ def iq_from_stream(stream, rng, noise):
     return iq
 
 
+def random_device_case(rng, stats):
+    """A random (mostly nonsensical) state machine -- every trigger kind, reset without
+    'always', zero-duration windows -- over random run lengths around its time constants."""
+    from tests.test_oracle import _random_fsm
+    rate = int(rng.choice([3000000, 1000000, 750000, 48000]))
+    od = _random_fsm(O, rng, rate)
+    d = ok.Device.from_tables(
+        max_bits=od.max_bits, sample_rate=rate, state_duration_us=od.state_duration_us,
+        state_timeout_us=od.state_timeout_us, trig_begin=od.trig_begin, trig_cond=od.trig_cond,
+        trig_action=od.trig_action, trig_next=od.trig_next, trig_duration_us=od.trig_duration_us)
+    scale = rate / 1e6
+    nruns = int(rng.integers(20, 2500 if rng.random() < 0.2 else 300))
+    runs = [max(1, int(rng.choice([30, 60, 100, 200, 250, 400, 1000, 5000]) * scale * rng.uniform(0.8, 1.2)))
+            for _ in range(nruns)]
+    stream = stream_from_runs(runs)
+    if stream.size > 1_000_000:
+        return
+    iq = iq_from_stream(stream, rng, noise=False)
+    spb = int(rng.choice([97, 512, 4096, 8192]))
+    want = O.rx(iq, None, 0.1, od, spb, msg_cap=1 << 20)
+    stats["cases"] += 1
+    stats["random_device_cases"] = stats.get("random_device_cases", 0) + 1
+    stats["messages"] += len(want.msg_samples)
+    stats["errors"] += len(want.err_samples)
+    for fsm_rounds, scan_sims in ((False, False), (False, True), (True, False)):
+        rx = ok.Receiver(None, d, max_samples=iq.size // 2, samples_per_buffer=spb, segment_buffers=2,
+                         message_slots=2 * spb * 2 + 2, message_capacity=1 << 20, edge_capacity=iq.size,
+                         fsm_rounds=fsm_rounds, scan_sims=scan_sims)
+        try:
+            got = rx.rx(iq)
+        except ok.OokdError as e:                   # a device that emits a message on (nearly) every sample
+            if "overflow" not in str(e):
+                raise
+            stats["overflows"] = stats.get("overflows", 0) + 1
+            rx.close()
+            continue
+        stats["receivers"] += 1
+        if not fsm_rounds:
+            stats["scan_runs"] += 1
+            if got.stats["fsm_path"] != 1:
+                stats["scan_refused"] += 1
+                key = "random device reason %#x%s" % (got.stats["fsm_fallback_reason"], " sims" if scan_sims else "")
+                stats["refusals"][key] = stats["refusals"].get(key, 0) + 1
+        good = (list(got.msg_samples) == list(want.msg_samples) and (got.payloads == want.payloads).all()
+                and got.stats["num_errors"] == len(want.err_samples))
+        if not good:
+            stats["mismatches"].append(dict(device="random", rate=rate, spb=spb, runs=[int(r) for r in runs[:400]],
+                                            fsm_rounds=fsm_rounds, scan_sims=scan_sims,
+                                            tables=dict(dur=[int(x) for x in od.state_duration_us],
+                                                        to=[int(x) for x in od.state_timeout_us],
+                                                        tb=[int(x) for x in od.trig_begin],
+                                                        cond=[int(x) for x in od.trig_cond],
+                                                        act=[int(x) for x in od.trig_action],
+                                                        nxt=[int(x) for x in od.trig_next],
+                                                        tdur=[int(x) for x in od.trig_duration_us],
+                                                        max_bits=int(od.max_bits)),
+                                            want=[int(x) for x in want.msg_samples[:20]],
+                                            got=[int(x) for x in got.msg_samples[:20]],
+                                            want_errors=len(want.err_samples), got_errors=int(got.stats["num_errors"])))
+        rx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--random-devices", type=float, default=0.0, help="share of cases run on random state machines")
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -103,6 +166,9 @@ def main():
         flts[name] = (ok.Filter.load(golden_path("filters", name)), O.load_filter_json(golden_path("filters", name)))
     last = time.time()
     while time.time() < t_end and len(stats["mismatches"]) < 5:
+        if args.random_devices and rng.random() < args.random_devices:
+            random_device_case(rng, stats)
+            continue
         name = str(rng.choice(list(SHAPES)))
         rate = int(rng.choice([3000000, 2000000, 1000000, 750000, 250000]))
         fname = rng.choice([None, None, "fs32_fs4", "fs128_fs16_dec4"])
