@@ -7,8 +7,12 @@
 // right after edge i the machine is fully described by a SMALL abstract
 // state
 //        (current state, number of collected bits)      [counter k = 0]
-// plus two "rest of this buffer is being skipped" states (device.c:646) and
-// one "assumption broken" state.  The effect of the samples between edge
+// plus two "rest of this buffer is being skipped" states (device.c:646),
+// one "assumption broken" state (poison), and -- for the edges on which NO
+// trigger fires although the state is timing something (a glitch inside a bit
+// gap) -- a few "stuck" twins STUCK_d(s): "was in (state, bits) = s d edges
+// ago and nothing has fired since", whose next leaf is simply the span table
+// row of s at the merged length (see kStuckDepth).  The effect of the samples between edge
 // i-1 and edge i (inclusive) is then a function L_i on that finite set; the
 // machine's trajectory is the prefix composition L_i o ... o L_1 applied to
 // the state after the first edge -- a scan, computed blockwise:
@@ -26,7 +30,7 @@
 //            list, the error list and the outgoing state.
 //
 // Everything is exact or refuses: if the true path ever leaves the abstract
-// model (an edge ignored by a state that is timing something, a span with
+// model (more ignored edges in a row than the stuck twins hold, a span with
 // too many events) the `fallback` word is set and the host reruns the
 // capture with the segment/round path of edges_fsm.hip, which handles
 // anything.  Both paths give identical results (tests run both against the
