@@ -14,6 +14,6 @@ cd $GRAFT_REPO_ROOT && timeout -k 10 400 python bench.py > $OUT/bench_line.json 
 timeout -k 10 300 python bench.py --no-quiet-skip --no-cpu-baseline > $OUT/bench_line_no_quiet_skip.json 2>> $OUT/bench.err &&
 timeout -k 10 300 python bench.py --filter fs128_fs16_dec4 --no-cpu-baseline > $OUT/bench_line_dec4.json 2>> $OUT/bench.err &&
 timeout -k 10 300 python bench.py --contexts 1 --no-cpu-baseline > $OUT/bench_line_one_context.json 2>> $OUT/bench.err &&
-timeout -k 10 300 python bench.py --contexts 3 --no-cpu-baseline > $OUT/bench_line_three_contexts.json 2>> $OUT/bench.err
+timeout -k 10 300 python bench.py --contexts 2 --no-cpu-baseline > $OUT/bench_line_two_contexts.json 2>> $OUT/bench.err
 find $OUT -name "*.csv" | head -20
 tail -1 $OUT/bench_line.json | cut -c1-300

@@ -57,7 +57,7 @@ def main():
             }, f, indent=1)
         print("traffic: %.4f GB per launch (algorithmic %.4f GB)" % (hbm / 1e9, ALGO_BYTES / 1e9))
     for name in ("bench_line", "bench_line_no_quiet_skip", "bench_line_dec4", "bench_line_one_context",
-                 "bench_line_three_contexts"):
+                 "bench_line_two_contexts"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p):
             with open(p) as f:
