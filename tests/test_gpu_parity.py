@@ -407,20 +407,15 @@ def test_g7_tolerance_boundaries(ok, oracle, vectors):
             rx.close()
 
 
-@pytest.mark.parametrize("devname", ["p3l-nexa2012", "unknown-remote1"])
-def test_glitches_inside_bit_gaps_stay_in_the_scan(ok, oracle, devname):
-    """A short pulse inside a bit gap: no trigger fires on its two edges (bit_off_time
-    has no window for them), the counter runs on and the next real edge is judged by the
-    whole gap -- the reference decodes the message as if nothing had happened.  The scan
-    form holds such stretches as "stuck" codes; with 70 messages and the glitch at a
-    different bit each time the stretches cross chunk (16 leaves), block (64) and group
-    (1024) boundaries.  Must not fall back, must equal the oracle."""
+def _glitchy_message_runs(devname, nmsg, seed):
+    """Run lengths of nmsg messages with 1-3 short pulses inside bit gaps each (placed
+    before any bit window opens, so the messages still decode)."""
     sh = {"p3l-nexa2012": dict(bits=36, start=500, first=8700, pulse=500, gap0=2000, gap1=4000),
           "unknown-remote1": dict(bits=32, start=8900, first=4400, pulse=550, gap0=550, gap1=1700)}[devname]
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(seed)
     us = RATE // 1000000
     runs = [5000]
-    for m in range(70):
+    for m in range(nmsg):
         runs += [sh["start"] * us, sh["first"] * us]
         bits = rng.integers(0, 2, size=sh["bits"])
         hit = {int(x) for x in rng.choice(sh["bits"], size=1 + m % 3, replace=False)}
@@ -434,6 +429,18 @@ def test_glitches_inside_bit_gaps_stay_in_the_scan(ok, oracle, devname):
             else:
                 runs.append(gap)
         runs += [sh["pulse"] * us, int(rng.integers(12000, 40000))]
+    return runs
+
+
+@pytest.mark.parametrize("devname", ["p3l-nexa2012", "unknown-remote1"])
+def test_glitches_inside_bit_gaps_stay_in_the_scan(ok, oracle, devname):
+    """A short pulse inside a bit gap: no trigger fires on its two edges (bit_off_time
+    has no window for them), the counter runs on and the next real edge is judged by the
+    whole gap -- the reference decodes the message as if nothing had happened.  The scan
+    form holds such stretches as "stuck" codes; with 70 messages and the glitch at a
+    different bit each time the stretches cross chunk (16 leaves), block (64) and group
+    (1024) boundaries.  Must not fall back, must equal the oracle."""
+    runs = _glitchy_message_runs(devname, 70, seed=77)
     iq = _iq_from_stream(stream_from_runs(runs))
     d = _dev(ok, devname)
     od = _odev(oracle, devname)
@@ -535,21 +542,19 @@ def test_batched_captures_are_independent(ok, oracle, vectors):
     assert total == len(got.msg_samples)
 
 
-@pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
-def test_sharded_capture_equals_whole(ok, oracle, vectors, filt):
+def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers):
     """One capture cut into shards (as 8 GPUs would hold it): halo + carried
     FSM state reproduce the single-pass result."""
     import torch
-    g, iq = _g1(vectors, noise_seed=21)
     of = _ofir(oracle, filt)
-    dec = of.total_decimation
+    dec = of.total_decimation if of else 1
     f = _flt(ok, filt)
-    d = _dev(ok, "p3l-nexa2012", RATE // dec)
-    od = _odev(oracle, "p3l-nexa2012", RATE // dec)
+    d = _dev(ok, devname, RATE // dec)
+    od = _odev(oracle, devname, RATE // dec)
     spb = 8192
     n = iq.size // 2
     want = oracle.rx(iq, of, 0.1, od, spb, want_bits=True)
-    shard = 40 * spb
+    shard = shard_buffers * spb
     bounds = list(range(0, n, shard)) + [n]
     nsh = len(bounds) - 1
     rxs, outs, bits = [], [None] * nsh, [None] * nsh
@@ -585,9 +590,24 @@ def test_sharded_capture_equals_whole(ok, oracle, vectors, filt):
         b = rxs[r].bits()
         assert (b == want.bits[off:off + b.size]).all(), r
         off += b.size
+        rxs[r].close()
     assert off == want.decimated
     assert msgs == list(want.msg_samples)
     assert pays == [bytes(p) for p in want.payloads]
+    return len(msgs)
+
+
+@pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
+def test_sharded_capture_equals_whole(ok, oracle, vectors, filt):
+    g, iq = _g1(vectors, noise_seed=21)
+    assert _check_sharded(ok, oracle, iq, filt, "p3l-nexa2012", 40) == 3
+
+
+def test_sharded_capture_with_glitches_inside_bit_gaps(ok, oracle):
+    """Shard boundaries that fall into messages whose bit gaps hold glitch pulses: a shard
+    may begin inside a stretch in which no trigger fires (carried counter != 0)."""
+    iq = _iq_from_stream(stream_from_runs(_glitchy_message_runs("p3l-nexa2012", 24, seed=5)))
+    assert _check_sharded(ok, oracle, iq, None, "p3l-nexa2012", 7) >= 20
 
 
 # ------------------------------------------------------- fine-grained APIs ----
