@@ -457,6 +457,21 @@ def test_glitches_inside_bit_gaps_stay_in_the_scan(ok, oracle, devname):
         rx.close()
 
 
+def test_short_randomised_differential_run():
+    """200 captures of tools/fuzz_gpu.py (fixed seed): jittered and glitched message
+    streams on the shipped devices, a third of them on random state machines; scan with
+    tables, scan with simulation and rounds, each against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "--cases", "200", "--seed", "5",
+                        "--random-devices", "0.3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["cases"] >= 200 and out["mismatches"] == []
+
+
 @pytest.mark.parametrize("segment_buffers", [1, 3, 0, -1])
 def test_reference_fsm_fixtures_random_streams(ok, oracle, vectors, segment_buffers):
     # segment_buffers >= 0: the round path with that segment size; -1: the scan path

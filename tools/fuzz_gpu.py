@@ -156,6 +156,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--random-devices", type=float, default=0.0, help="share of cases run on random state machines")
     ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many captures (0 = run for --seconds)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
@@ -165,7 +166,7 @@ def main():
     for name in ("fs32_fs4", "fs128_fs16_dec4"):
         flts[name] = (ok.Filter.load(golden_path("filters", name)), O.load_filter_json(golden_path("filters", name)))
     last = time.time()
-    while time.time() < t_end and len(stats["mismatches"]) < 5:
+    while (stats["cases"] < args.cases if args.cases else time.time() < t_end) and len(stats["mismatches"]) < 5:
         if args.random_devices and rng.random() < args.random_devices:
             random_device_case(rng, stats)
             continue
