@@ -557,6 +557,36 @@ def test_batched_captures_are_independent(ok, oracle, vectors):
     assert total == len(got.msg_samples)
 
 
+def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle):
+    """Six independent captures in one call, each with stuck stretches (and the first edges of
+    a capture right behind one): per capture the oracle's messages, all in the scan form."""
+    import torch
+    caps = [_iq_from_stream(stream_from_runs(_glitchy_message_runs("p3l-nexa2012", 6 + c, seed=300 + c)))
+            for c in range(6)]
+    n = max(x.size // 2 for x in caps)
+    n += (-n) % 4
+    stride = n + 8
+    host = np.zeros((len(caps), 2 * stride), dtype=np.int16)
+    for c, x in enumerate(caps):
+        host[c, :x.size] = x
+    dev_t = torch.from_numpy(host).cuda()
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
+    got = rx.rx_device(dev_t.data_ptr(), n, num_captures=len(caps), stride=stride)
+    assert got.stats["fsm_path"] == 1, got.stats["fsm_fallback_reason"]
+    total = 0
+    for c in range(len(caps)):
+        want = oracle.rx(host[c, :2 * n], None, 0.1, od, 8192)
+        gc = got.for_capture(c)
+        assert list(gc.msg_samples) == list(want.msg_samples), c
+        assert (gc.payloads == want.payloads).all(), c
+        assert len(want.msg_samples) >= 5 + c
+        total += len(want.msg_samples)
+    assert total == len(got.msg_samples)
+    rx.close()
+
+
 def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers):
     """One capture cut into shards (as 8 GPUs would hold it): halo + carried
     FSM state reproduce the single-pass result."""
