@@ -15,6 +15,8 @@
 // multiply-adds are written explicitly with __builtin_fmaf.
 #include "kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -966,12 +968,22 @@ uint32_t front_tile_bits(const FrontParams &p) {
     return 0;
 }
 
-hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream) {
-    if (p.n_out == 0) return hipSuccess;
+// t0 / t1 (optional): events that take the kernel's own start / end time stamps.  For the
+// one-kernel front ends they ride on the dispatch itself (hipExtLaunchKernel): no marker
+// packets in front of and behind the dominant kernel, and their difference is the kernel's
+// duration as a profiler sees it.
+hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream,
+                        hipEvent_t t0, hipEvent_t t1) {
+    if (p.n_out == 0) {
+        if (t0 && hipEventRecord(t0, stream) != hipSuccess) return hipGetLastError();
+        if (t1 && hipEventRecord(t1, stream) != hipSuccess) return hipGetLastError();
+        return hipSuccess;
+    }
     if (p.num_stages == 0) {
         // whole 4096-sample blocks, so every bit word of the capture is written
         const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * kFirWaves;
-        hipLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)tiles, num_captures), dim3(64), 0, stream, p);
+        hipExtLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)tiles, num_captures), dim3(64), 0, stream, t0, t1, 0,
+                              p);
         return hipGetLastError();
     }
     if (use_fir1(p)) {
@@ -993,7 +1005,7 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
             if (e != hipSuccess) return e;
             FrontParams pp = p;
             void *args[] = {&pp};
-            e = hipLaunchKernel(fn, grid, dim3(64 * kFirWgWaves), args, lds, stream);
+            e = hipExtLaunchKernel(fn, grid, dim3(64 * kFirWgWaves), args, lds, stream, t0, t1, 0);
             if (e != hipSuccess) return e;
             return hipGetLastError();
         }
@@ -1003,13 +1015,18 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         const uint64_t tiles = (p.n_out + (uint64_t)kFir2Waves * Fir2Dec4::F - 1) / ((uint64_t)kFir2Waves * Fir2Dec4::F);
         const dim3 grid((uint32_t)tiles, num_captures), block(64 * kFir2Waves);
         if (exact) {
-            hipLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, true>), grid, block, lds, stream, p);
+            hipExtLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, true>), grid, block, lds, stream, t0, t1, 0, p);
         } else {
-            hipLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, false>), grid, block, lds, stream, p);
+            hipExtLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, false>), grid, block, lds, stream, t0, t1, 0, p);
         }
         return hipGetLastError();
     }
-    return launch_front_generic(p, num_captures, stream);
+    // several kernels: bracket them
+    if (t0 && hipEventRecord(t0, stream) != hipSuccess) return hipGetLastError();
+    const hipError_t e = launch_front_generic(p, num_captures, stream);
+    if (e != hipSuccess) return e;
+    if (t1 && hipEventRecord(t1, stream) != hipSuccess) return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream) {

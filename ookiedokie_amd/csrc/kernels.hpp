@@ -69,8 +69,8 @@ struct FrontParams {
 // more than it was last granted (the call costs microseconds per launch).
 hipError_t ensure_dynamic_lds(const void *func, size_t bytes);
 
-hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
-                        hipStream_t stream);
+hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream,
+                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // 1024-ish output windows ("wave tiles") the tuned kernels split a capture into
 // (0 when the generic kernel serves this shape).
 uint64_t front_wave_tiles(const FrontParams &p);

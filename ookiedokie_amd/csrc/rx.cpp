@@ -499,9 +499,7 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
     hipEvent_t gate = nullptr;
     if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) gate = front_gate(dev);
     if (gate) HIPCHK(hipStreamWaitEvent(stream, gate, 0));
-    HIPCHK(hipEventRecord(ev[0], stream));
-    HIPCHK(launch_front(fp, run_caps, exact, stream));
-    HIPCHK(hipEventRecord(ev[1], stream));
+    HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));    // ev[0], ev[1]: the kernel's own time stamps
     if (gate) HIPCHK(hipEventRecord(gate, stream));
     if (run_n_out > 0) HIPCHK(launch_edges(edge_params(), stream));
     return OOKD_OK;
