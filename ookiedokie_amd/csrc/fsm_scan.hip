@@ -37,6 +37,8 @@
 // oracle).
 #include "kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -2133,7 +2135,7 @@ uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB) {
 
 uint32_t fsm_scan_fin_block() { return (uint32_t)kFinBlock; }
 
-hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
+hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end) {
     ScanParams sp{};
     sp.f = a.f;
     sp.block_tab = a.block_tab;
@@ -2191,7 +2193,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
-    hipLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, sp, a.publish);
+    // t_end takes the last kernel's own end time stamp (no marker packet behind the chain)
+    hipExtLaunchKernelGGL(fin_msg_kernel, dim3(64), dim3(256), 0, stream, nullptr, t_end, 0, sp, a.publish);
     return hipGetLastError();
 }
 

@@ -264,7 +264,8 @@ bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim,
                        std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach,
                        std::vector<uint16_t> &stuck_src, std::vector<uint8_t> &stuck_rows);
 uint32_t fsm_scan_fin_block();
-hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream);
+// t_end (optional): event that takes the end time stamp of the scan's last kernel
+hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end = nullptr);
 
 // ---- workgroup inclusive sum (device code) ---------------------------------------------
 // Shuffles inside each wavefront + one exchange of the wave totals through

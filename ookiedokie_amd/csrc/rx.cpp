@@ -651,9 +651,8 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.run_stamp = scan_stamp;
     a.fin_blocks_cap = scan_fin_cap;
     // totals / scan_fallback are still zero from the header memset of front_and_edges
-    HIPCHK(launch_fsm_scan(a, stream));
+    HIPCHK(launch_fsm_scan(a, stream, ev[2]));      // ev[2]: end of its last kernel
     scan_published = true;          // its last kernel also publishes
-    HIPCHK(hipEventRecord(ev[2], stream));
     static const char *const debug_scan = getenv("OOKD_DEBUG_SCAN");     // read once: this is the hot path
     if (debug_scan) HIPCHK(hipStreamSynchronize(stream));
     if (debug_scan && d_debug.p) {
