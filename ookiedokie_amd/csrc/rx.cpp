@@ -50,19 +50,17 @@ struct ResultHeader {
 // Front-end kernels of different contexts on one device take turns: they are
 // HBM bound, so running two at once only makes both slower, while everything
 // after them (edges, state machine: latency bound) overlaps the next
-// context's front end.  One event per device, re-recorded after every front
-// kernel; a context waits for the latest record before launching its own.
+// context's front end.  Per device the stop event of the front-end kernel queued
+// last is remembered (it rides on that kernel's dispatch: launch_front); a context
+// makes its stream wait for it before launching its own -- no marker packets.
 constexpr int kMaxGateDevices = 64;
 std::atomic<int> g_live_contexts[kMaxGateDevices];
 
-hipEvent_t front_gate(int dev) {
-    static std::mutex m;
-    static hipEvent_t ev[kMaxGateDevices] = {};
-    if (dev < 0 || dev >= kMaxGateDevices) return nullptr;
-    std::lock_guard<std::mutex> lock(m);
-    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
-    return ev[dev];
-}
+struct FrontGate {
+    std::mutex m;
+    hipEvent_t last[kMaxGateDevices] = {};
+};
+FrontGate g_gate;
 
 template <typename T>
 struct DevBuf {
@@ -335,6 +333,10 @@ struct ookd_rx {
     bool counted = false;           // this context is in g_live_contexts
     ~ookd_rx() {
         if (counted && dev >= 0 && dev < kMaxGateDevices) g_live_contexts[dev].fetch_sub(1);
+        if (dev >= 0 && dev < kMaxGateDevices) {
+            std::lock_guard<std::mutex> lock(g_gate.m);
+            if (g_gate.last[dev] == ev[1]) g_gate.last[dev] = nullptr;      // ev[1] is destroyed below
+        }
         (void)hipSetDevice(dev);
         d_taps.release();
         d_tables.release();
@@ -496,11 +498,17 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
-    hipEvent_t gate = nullptr;
-    if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) gate = front_gate(dev);
-    if (gate) HIPCHK(hipStreamWaitEvent(stream, gate, 0));
-    HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));    // ev[0], ev[1]: the kernel's own time stamps
-    if (gate) HIPCHK(hipEventRecord(gate, stream));
+    if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
+        // wait + launch + publish under the lock: the event must be on its way before another
+        // context may wait for it
+        std::lock_guard<std::mutex> lock(g_gate.m);
+        hipEvent_t prev = g_gate.last[dev];
+        if (prev && prev != ev[1]) HIPCHK(hipStreamWaitEvent(stream, prev, 0));
+        HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));
+        g_gate.last[dev] = ev[1];
+    } else {
+        HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));    // ev[0], ev[1]: the kernel's own time stamps
+    }
     if (run_n_out > 0) HIPCHK(launch_edges(edge_params(), stream));
     return OOKD_OK;
 }
