@@ -168,7 +168,11 @@ enum {
     /* State machine scan: simulate every span instead of looking its result
      * up in the per-device span tables built at create time (identical
      * results; exists so the tests can run both). */
-    OOKD_RX_SCAN_SIMS = 1u << 5
+    OOKD_RX_SCAN_SIMS = 1u << 5,
+    /* Front end: launch one workgroup per wave tile (the round-1 form) instead
+     * of the persistent streaming grid that pulls batches of tiles from ticket
+     * heads (identical bits; exists so the tests can run both). */
+    OOKD_RX_FRONT_GRID = 1u << 6
 };
 
 typedef struct ookd_rx_config {

@@ -41,6 +41,7 @@ RX_FSM_ROUNDS = 4
 RX_NO_QUIET_SKIP = 8
 RX_COUNT_QUIET = 16
 RX_SCAN_SIMS = 32
+RX_FRONT_GRID = 64
 DEFAULT_THRESHOLD = 0.1                 # ookiedokie_cfg.c:27
 DEFAULT_RATE = 3000000                  # ookiedokie_cfg.c:32
 DEFAULT_SAMPLES_PER_BUF = 8192          # ookiedokie_cfg.c:34
@@ -509,12 +510,14 @@ class Receiver:
                  max_captures: int = 1, exact_fir: bool = False, keep_fir: bool = False,
                  edge_capacity: int = 0, segment_buffers: int = 0, message_slots: int = 0,
                  message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
-                 quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False):
+                 quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False,
+                 front_grid: bool = False):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
                      | (RX_FSM_ROUNDS if fsm_rounds else 0) | (0 if quiet_skip else RX_NO_QUIET_SKIP)
-                     | (RX_COUNT_QUIET if count_quiet else 0) | (RX_SCAN_SIMS if scan_sims else 0))
+                     | (RX_COUNT_QUIET if count_quiet else 0) | (RX_SCAN_SIMS if scan_sims else 0)
+                     | (RX_FRONT_GRID if front_grid else 0))
         cfg.threshold = threshold
         cfg.samples_per_buffer = samples_per_buffer
         cfg.max_samples = max_samples

@@ -49,7 +49,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(HERE, "lib", os.path.basename(src) + ".o")
         cmd = [_hipcc(), "-x", "hip", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
-               "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result",
+               "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-uninitialized",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
                "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -109,6 +109,21 @@ __host__ __device__ __forceinline__ uint32_t fir1_wave_slots(uint32_t Tp) {
 
 // Sequential, unfused recomputation of one output (guard-band path).
 template <int R>
+__device__ __forceinline__ float2 fir1_exact_body(const float2 *lds, uint32_t j_out,
+                                                const float *taps, uint32_t ntaps) {
+    float re = 0.0f, im = 0.0f;
+    for (uint32_t k = 0; k < ntaps; ++k) {
+        const float2 x = lds[slot<R>(j_out - k)];
+        const float t = taps[k];
+        const float pr = t * x.x;
+        const float pi = t * x.y;
+        re = re + pr;
+        im = im + pi;
+    }
+    return make_float2(re, im);
+}
+
+template <int R>
 __device__ __noinline__ float2 fir1_exact_output(const float2 *lds, uint32_t j_out,
                                                  const float *taps, uint32_t ntaps) {
     float re = 0.0f, im = 0.0f;
@@ -173,85 +188,25 @@ __device__ __forceinline__ void fir1_chunk(v2f *acc, const v2f *tpair, const v2f
 }
 
 typedef short v2s __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// non-temporal 16 B load: the capture is streamed through once (tools/stream_bw.hip: +7 % over plain loads)
+__device__ __forceinline__ uint4 ld_nt4(const uint4 *p) {
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 __device__ __forceinline__ v2s as_v2s(uint32_t w) { return __builtin_bit_cast(v2s, w); }
 
-template <bool EXACT, int R>
-__global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const FrontParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-
-    constexpr uint32_t kTile = 64u * R;                 // outputs per wavefront
-    constexpr int kRounds = (kTile + 256 + 255) / 256;  // 16 B loads per lane (taps <= 256)
-    const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kTile;
-    const uint32_t Tp = p.stage[0].ntaps_pad;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
-    float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots<R>(Tp);
-    uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-
-    // ---- load the wave's window: slot j <-> input index t0 - Tp + j ------------
-    // 64R + Tp samples in vectors of 4, lane + 64*i, kept RAW in
-    // registers until the quiet test has decided whether they are needed.
-    const uint32_t nvec = (kTile + Tp) >> 2;
-    const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-    const bool interior = aligned16 && t0 >= Tp && t0 + kTile <= p.n_valid;
-    if (interior) {
-        const uint4 *src4 = reinterpret_cast<const uint4 *>(src + (t0 - Tp));
-        uint4 q[kRounds];
-#pragma unroll
-        for (int i = 0; i < kRounds; ++i) {
-            const uint32_t v = tid + 64u * i;
-            q[i] = (64u * (i + 1) <= kTile / 4 || v < nvec) ? src4[v] : make_uint4(0, 0, 0, 0);
-        }
-        // ---- quiet test ----------------------------------------------------------
-        // |y_re|,|y_im| <= sum|h| * max|component|, so a wave whose whole window
-        // stays below quiet_lsb cannot reach the threshold: its 1024 bits are 0
-        // without running the filter -- exactly what the reference computes.
-        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
-#pragma unroll
-        for (int i = 0; i < kRounds; ++i) {
-            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].x), as_v2s(q[i].y)));
-            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].z), as_v2s(q[i].w)));
-            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].x), as_v2s(q[i].y)));
-            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].z), as_v2s(q[i].w)));
-        }
-        const int L = p.quiet_lsb;
-        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
-        if (!p.fir_out && __ballot(loud) == 0) {
-            if (tid < kTile / 64) words[(t0 >> 6) + tid] = 0;
-            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = 0;
-            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < kRounds; ++i) {
-            const uint32_t v = tid + 64u * i;
-            if (64u * (i + 1) <= kTile / 4 || v < nvec) {
-                float2 *dst = lds + slot<R>(4 * v);        // 4 slots, never straddle a pad
-                dst[0] = unpack_iq(q[i].x);
-                dst[1] = unpack_iq(q[i].y);
-                dst[2] = unpack_iq(q[i].z);
-                dst[3] = unpack_iq(q[i].w);
-            }
-        }
-    } else {
-        // first / last tiles of a capture, halo, unaligned host pointers
-        for (uint32_t v = tid; v < nvec; v += 64) {
-            const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
-            float2 *dst = lds + slot<R>(4 * v);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = fetch_sample(p, src, nullptr, n + i);
-        }
-    }
-    // the window is private to this wavefront and the LDS executes one wave's
-    // accesses in order: no workgroup barrier, only keep the compiler from
-    // moving reads above the writes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
+// Everything behind the staged window of one wave tile: packed MACs over the
+// tap chunks, threshold + guard band, bit packing, optional float output.
+// Stores the tile's bit words (WT: write-through, visible to a kernel that
+// starts while this one still runs) and returns the tile info word
+// (level changes inside the tile | first bit << 30 | last bit << 31).
+template <bool EXACT, int R, bool WT, bool NOCALL = false>
+__device__ __forceinline__ uint32_t fir1_tile_compute(const FrontParams &p, float2 *lds, uint32_t Tp, uint64_t t0,
+                                                      uint32_t tid, uint32_t cap, uint64_t *words) {
+    uint32_t info = 0;
     // ---- accumulate ----------------------------------------------------------
     v2f acc[R];
 #pragma unroll
@@ -313,18 +268,24 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
     if (!EXACT && any_unsure != 0) {
         // some lane of this wave has a sample inside the band: those lanes redo
         // their borderline samples in the reference's exact order
-        uint32_t redo = 0;
+        uint32_t todo = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             v2f sq;
             asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sq) : "v"(acc[r]));
             const float pf = sq.x + sq.y;
-            if (pf >= p.p_lo && !(pf >= p.p_hi) && o0 + r < p.n_out) {
-                const float2 y = fir1_exact_output<R>(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps);
-                const float pe = power_ref(y.x, y.y);
-                mask = (mask & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
-                redo++;
-            }
+            if (pf >= p.p_lo && !(pf >= p.p_hi) && o0 + r < p.n_out) todo |= 1u << r;
+        }
+        const uint32_t redo = (uint32_t)__popc(todo);
+        while (todo) {                          // one copy of the recompute, whichever outputs need it
+            const uint32_t r = (uint32_t)__ffs((int)todo) - 1u;
+            todo &= todo - 1u;
+            // (NOCALL: the streaming kernel keeps loads in flight in registers the compiler does not
+            //  know to be busy -- nothing may save / restore them around a call)
+            const float2 y = NOCALL ? fir1_exact_body<R>(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps)
+                                    : fir1_exact_output<R>(lds, Tp + R * tid + r, p.taps, p.stage[0].ntaps);
+            const float pe = power_ref(y.x, y.y);
+            mask = (mask & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
         }
         if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
     }
@@ -355,7 +316,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> (R - 1)) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = cnt | (first << 30) | (last << 31);
+        info = cnt | (first << 30) | (last << 31);
     }
 
     // 64 / R lanes x R bits -> one 64-bit word
@@ -366,7 +327,311 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         const uint32_t lo = __shfl_xor((uint32_t)w64, (int)d), hi = __shfl_xor((uint32_t)(w64 >> 32), (int)d);
         w64 |= (uint64_t)lo | ((uint64_t)hi << 32);
     }
-    if (tid % kLanesPerWord == 0) words[(t0 >> 6) + tid / kLanesPerWord] = w64;
+    if (tid % kLanesPerWord == 0) {
+        if (WT) __hip_atomic_store(words + (t0 >> 6) + tid / kLanesPerWord, w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else words[(t0 >> 6) + tid / kLanesPerWord] = w64;
+    }
+    return info;
+}
+
+template <bool EXACT, int R>
+__global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    constexpr uint32_t kTile = 64u * R;                 // outputs per wavefront
+    constexpr int kRounds = (kTile + 256 + 255) / 256;  // 16 B loads per lane (taps <= 256)
+    const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t cap = blockIdx.y;
+    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kTile;
+    const uint32_t Tp = p.stage[0].ntaps_pad;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
+    float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots<R>(Tp);
+    uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+
+    // ---- load the wave's window: slot j <-> input index t0 - Tp + j ------------
+    // 64R + Tp samples in vectors of 4, lane + 64*i, kept RAW in
+    // registers until the quiet test has decided whether they are needed.
+    const uint32_t nvec = (kTile + Tp) >> 2;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    const bool interior = aligned16 && t0 >= Tp && t0 + kTile <= p.n_valid;
+    if (interior) {
+        const uint4 *src4 = reinterpret_cast<const uint4 *>(src + (t0 - Tp));
+        uint4 q[kRounds];
+#pragma unroll
+        for (int i = 0; i < kRounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            q[i] = (64u * (i + 1) <= kTile / 4 || v < nvec) ? ld_nt4(src4 + v) : make_uint4(0, 0, 0, 0);     // read once
+        }
+        // ---- quiet test ----------------------------------------------------------
+        // |y_re|,|y_im| <= sum|h| * max|component|, so a wave whose whole window
+        // stays below quiet_lsb cannot reach the threshold: its 1024 bits are 0
+        // without running the filter -- exactly what the reference computes.
+        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+#pragma unroll
+        for (int i = 0; i < kRounds; ++i) {
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2s(q[i].z), as_v2s(q[i].w)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].x), as_v2s(q[i].y)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2s(q[i].z), as_v2s(q[i].w)));
+        }
+        const int L = p.quiet_lsb;
+        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+        if (!p.fir_out && __ballot(loud) == 0) {
+            // sparse output: the tile's words and info are zero already (launch_clear_tiles)
+            if (!p.sparse) {
+                if (tid < kTile / 64) words[(t0 >> 6) + tid] = 0;
+                if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = 0;
+            }
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < kRounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            if (64u * (i + 1) <= kTile / 4 || v < nvec) {
+                float2 *dst = lds + slot<R>(4 * v);        // 4 slots, never straddle a pad
+                dst[0] = unpack_iq(q[i].x);
+                dst[1] = unpack_iq(q[i].y);
+                dst[2] = unpack_iq(q[i].z);
+                dst[3] = unpack_iq(q[i].w);
+            }
+        }
+    } else {
+        // first / last tiles of a capture, halo, unaligned host pointers
+        for (uint32_t v = tid; v < nvec; v += 64) {
+            const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
+            float2 *dst = lds + slot<R>(4 * v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = fetch_sample(p, src, nullptr, n + i);
+        }
+    }
+    // the window is private to this wavefront and the LDS executes one wave's
+    // accesses in order: no workgroup barrier, only keep the compiler from
+    // moving reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint32_t info = fir1_tile_compute<EXACT, R, false>(p, lds, Tp, t0, tid, cap, words);
+    if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = info;
+}
+
+// ---------------------------------------------------------------------------
+// front end, 1 stage / decimation 1, STREAMING form
+// ---------------------------------------------------------------------------
+//
+// The grid form above is one workgroup per wave tile: half a million tiny
+// workgroups per GiB, which fill every wave slot and nearly all of the LDS of
+// every CU for as long as the grid lasts -- the edge / state machine kernels
+// of the chunk (or capture) before starve beside it.  This form is a
+// PERSISTENT grid of single-wave workgroups, N per CU (the launcher picks N),
+// that pull GROUPS of kStreamGroup = 4 consecutive tiles (2048 outputs, 8 KiB
+// of input) from ticket heads:
+//   * many heads (head = workgroup % H owns the groups = head mod H): one
+//     returning atomic per group, far below what a head sustains, and the
+//     active window of the capture stays dense and moves front to back like a
+//     hardware-dispatched grid's (tools/stream_bw.hip: 6.6-6.7 TB/s at 8..32
+//     waves per CU against 6.9 for the grid shape and 5.3-6.2 for strided or
+//     few-head persistent shapes);
+//   * residency is capped at N waves and N windows of LDS per CU: the rest of
+//     the CU stays free for whatever else is queued on the device;
+//   * a wave issues the nine loads of its group at once (nt: the stream is read
+//     once; 8.5 KiB in flight per waiting wave) with the ticket of its next
+//     group in front of them; inside a group the tap history of a tile is the
+//     tail of the tile before, in registers;
+//   * a quiet group costs its loads, ONE store of zero words and ONE store of
+//     tile infos;
+//   * chunk pipelining: a wave counts the groups it finished per chunk and adds
+//     them to done[chunk] when it moves on to a later chunk (its stores are
+//     write-through and complete by then), so a stream waiting for
+//     done[c] == groups of chunk c may read that prefix of the bit words while
+//     this kernel still runs.
+// Tile arithmetic is the grid form's (fir1_tile_compute), bit for bit.
+// (Deeper software pipelines -- a ring of tiles in registers, double-buffered
+//  groups -- were tried: the compiler's wait counts turn conservative across the
+//  loop (vmcnt(0) behind the issue), and inline-asm loads are unsafe because the
+//  register allocator copies their destination registers while they are in flight.)
+
+struct StreamGroup {            // raw samples of one group: lane L of c[i][0] holds samples 512 i + 4L .., c[i][1] + 256
+    v4u c[kStreamGroup][2];
+    v4u hal;                    // lanes hal0..63: the Tp samples before the group
+};
+
+__device__ __forceinline__ v4u ld_nt(const uint4 *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p));
+}
+
+constexpr uint32_t kNoGroup = 0xffffffffu;
+
+template <bool EXACT, bool WT>
+__global__ __launch_bounds__(64) void fir1_stream_kernel(const FrontParams p, const StreamCtl ctl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int R = kFir1RShort;
+    constexpr uint32_t kTile = 64u * R;                 // 512 outputs
+    constexpr uint32_t kGroupOut = kTile * kStreamGroup;
+    static_assert(kTile == 512, "two 16 B loads per lane and tile");
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Tp = p.stage[0].ntaps_pad;           // <= 256
+    const uint32_t hal0 = 64u - Tp / 4u;                // lanes hal0 .. 63 of a history register are valid
+    float2 *lds = reinterpret_cast<float2 *>(smem_raw);
+    const uint32_t H = ctl.num_heads;
+    const uint32_t h = blockIdx.x % H;
+    uint32_t *head = ctl.heads + (size_t)kStreamHeadStride * h;
+    const uint32_t ngroups = ctl.groups_per_cap * ctl.num_caps;
+    const int L = p.quiet_lsb;
+    const bool do_quiet = L > 0 && !p.fir_out;
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(p.iq) & 15u) == 0 && (p.cap_stride & 3u) == 0;
+
+    // (lane 0 only, written over the zero the other lanes keep -- no merge instruction, so the wait for the atomic
+    //  falls where the ticket is resolved.  The build disables the compiler's atomic optimizer,
+    //  which would rewrite this as a wave reduction and wait for the result on the spot.)
+    auto issue_ticket = [&]() {
+        uint32_t t = 0;
+        if (tid == 0) t = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    };
+    auto resolve_ticket = [&](uint32_t t) {
+        const uint64_t g = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t) * H + h;
+        return g < ngroups ? (uint32_t)g : kNoGroup;
+    };
+
+    // chunk accounting (write-through runs): groups this wave finished in chunk `chunk`
+    uint32_t chunk = 0, chunk_count = 0;
+    auto flush_chunk = [&]() {
+        if (WT && ctl.done && chunk_count) {
+            // every store of those groups has reached memory before the chunk counter moves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_fetch_add(ctl.done + chunk, chunk_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        chunk_count = 0;
+    };
+
+    uint32_t g = resolve_ticket(issue_ticket());
+    while (g != kNoGroup) {
+        const uint32_t t_next = issue_ticket();         // returns while the group's loads are waited for
+        const uint32_t cap = g / ctl.groups_per_cap;
+        const uint64_t g0 = (uint64_t)(g - cap * ctl.groups_per_cap) * kGroupOut;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
+        uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+        // a group whose window lies inside the capture and can be fetched 16 B at a time
+        const bool inside = aligned16 && g0 >= Tp && g0 + kGroupOut <= p.n_valid;
+        StreamGroup q{};
+        if (inside) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + g0) + tid;
+#pragma unroll
+            for (int i = 0; i < kStreamGroup; ++i) {
+                q.c[i][0] = ld_nt(s4 + 128 * i);
+                q.c[i][1] = ld_nt(s4 + 128 * i + 64);
+            }
+            q.hal = ld_nt(s4 - 64);     // (lanes below hal0 fetch samples further back: never used)
+        }
+        uint32_t quiet_mask = 0, info_vec = 0;
+        bool info_vec_any = false;
+#pragma unroll
+        for (int i = 0; i < kStreamGroup; ++i) {
+            const uint64_t t0 = g0 + (uint64_t)i * kTile;
+            const v4u hal = i == 0 ? q.hal : q.c[i > 0 ? i - 1 : 0][1];    // the tile's tap history: the tail of the tile before
+            bool loud = true;
+            if (inside) {
+                if (do_quiet) {
+                    v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+                    const uint32_t w[12] = {q.c[i][0].x, q.c[i][0].y, q.c[i][0].z, q.c[i][0].w, q.c[i][1].x, q.c[i][1].y,
+                                            q.c[i][1].z, q.c[i][1].w, hal.x,       hal.y,       hal.z,       hal.w};
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        // lanes below hal0 hold no history (older samples: masked)
+                        const uint32_t v = (k >= 8 && tid < hal0) ? 0u : w[k];
+                        mx = __builtin_elementwise_max(mx, as_v2s(v));
+                        mn = __builtin_elementwise_min(mn, as_v2s(v));
+                    }
+                    loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+                    loud = __ballot(loud) != 0;
+                }
+                if (loud) {
+                    // window slot j <-> input index t0 - Tp + j
+                    if (tid >= hal0) {
+                        float2 *dst = lds + slot<R>(4u * (tid - hal0));
+                        dst[0] = unpack_iq(hal.x);
+                        dst[1] = unpack_iq(hal.y);
+                        dst[2] = unpack_iq(hal.z);
+                        dst[3] = unpack_iq(hal.w);
+                    }
+                    float2 *d0 = lds + slot<R>(Tp + 4u * tid);
+                    d0[0] = unpack_iq(q.c[i][0].x);
+                    d0[1] = unpack_iq(q.c[i][0].y);
+                    d0[2] = unpack_iq(q.c[i][0].z);
+                    d0[3] = unpack_iq(q.c[i][0].w);
+                    float2 *d1 = lds + slot<R>(Tp + 256u + 4u * tid);
+                    d1[0] = unpack_iq(q.c[i][1].x);
+                    d1[1] = unpack_iq(q.c[i][1].y);
+                    d1[2] = unpack_iq(q.c[i][1].z);
+                    d1[3] = unpack_iq(q.c[i][1].w);
+                }
+            } else {
+                // first / last groups of a capture, halo of a shard, unaligned pointers
+                const uint32_t nvec = (kTile + Tp) >> 2;
+                for (uint32_t v = tid; v < nvec; v += 64) {
+                    const int64_t n = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
+                    float2 *dst = lds + slot<R>(4 * v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dst[k] = fetch_sample(p, src, nullptr, n + k);
+                }
+            }
+            if (loud) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t info = fir1_tile_compute<EXACT, R, WT, true>(p, lds, Tp, t0, tid, cap, words);
+                if (tid == (uint32_t)i) info_vec = info;
+                info_vec_any = info_vec_any || info != 0;
+                // the next loud tile rewrites the window: the reads above are done (the LDS is in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                quiet_mask |= 1u << i;
+            }
+        }
+        // sparse output (p.sparse): quiet tiles store nothing -- their words and infos are zero already
+        // (launch_clear_tiles); small stores into the read stream cost 3 x their share of the bytes
+        // (tools/stream_bw2.hip).  Loud tiles' words were stored by fir1_tile_compute.
+        if (!p.sparse) {
+            // zero words of the quiet tiles: 8 words per tile, lane l covers words 2l, 2l+1 of the group = tile l / 4
+            if (tid < 4u * kStreamGroup && ((quiet_mask >> (tid >> 2)) & 1u)) {
+                uint64_t *w = words + (g0 >> 6) + 2u * tid;
+                if (WT) {
+                    __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(w + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *reinterpret_cast<uint4 *>(w) = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if (tid < (uint32_t)kStreamGroup) {
+                uint32_t *ti = p.tile_info + (uint64_t)cap * p.tiles_per_cap + (g0 / kTile) + tid;
+                if (WT) __hip_atomic_store(ti, info_vec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *ti = info_vec;
+            }
+        } else if (info_vec_any) {
+            // infos of the loud tiles only (lane i holds tile i's)
+            if (tid < (uint32_t)kStreamGroup && !((quiet_mask >> tid) & 1u)) {
+                uint32_t *ti = p.tile_info + (uint64_t)cap * p.tiles_per_cap + (g0 / kTile) + tid;
+                if (WT) __hip_atomic_store(ti, info_vec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *ti = info_vec;
+            }
+        }
+        if (p.quiet_count && tid == 0 && quiet_mask) atomicAdd(p.quiet_count + (g % kQuietCounters), (uint32_t)__popc(quiet_mask));
+        if (WT && ctl.done) {
+            uint32_t c = chunk;
+            while (c + 1 < ctl.num_chunks && g >= ctl.chunk_end[c]) ++c;
+            if (c != chunk) {
+                flush_chunk();
+                chunk = c;
+            }
+            chunk_count++;
+        }
+        g = resolve_ticket(t_next);
+    }
+    flush_chunk();
 }
 
 // ---------------------------------------------------------------------------
@@ -1027,6 +1292,97 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
     if (e != hipSuccess) return e;
     if (t1 && hipEventRecord(t1, stream) != hipSuccess) return hipGetLastError();
     return hipSuccess;
+}
+
+bool front_sparse_capable(const FrontParams &p) {
+    return use_fir1(p) && p.quiet_lsb > 0 && !p.fir_out;
+}
+
+bool front_streams(const FrontParams &p) {
+    return use_fir1(p) && fir1_R(p) == kFir1RShort && p.stage[0].ntaps_pad <= 256u;
+}
+
+static int device_cu_count() {
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        cached = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                     ? prop.multiProcessorCount : 256;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
+hipError_t launch_front_stream(const FrontParams &p, StreamCtl ctl, bool exact, bool write_through,
+                               hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
+    if (!front_streams(p) || p.tiles_per_cap % kStreamGroup != 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)fir1_wave_slots<kFir1RShort>(p.stage[0].ntaps_pad) * sizeof(float2);
+    const uint64_t ngroups = (uint64_t)(p.tiles_per_cap / kStreamGroup) * ctl.num_caps;
+    if (ngroups >= 0xfffffff0ull) return hipErrorInvalidValue;
+    if (ngroups == 0) {
+        if (t0 && hipEventRecord(t0, stream) != hipSuccess) return hipGetLastError();
+        if (t1 && hipEventRecord(t1, stream) != hipSuccess) return hipGetLastError();
+        return hipSuccess;
+    }
+    ctl.groups_per_cap = p.tiles_per_cap / kStreamGroup;
+    uint64_t grid = (uint64_t)device_cu_count() * (ctl.waves_per_cu ? ctl.waves_per_cu : 12u);
+    if (grid > ngroups) grid = ngroups;
+    // heads: as many as the grid has waves (each head still hands out groups in order), at most kStreamHeads
+    ctl.num_heads = (uint32_t)std::min<uint64_t>(grid, (uint64_t)kStreamHeads);
+    const void *fn;
+    if (write_through) {
+        fn = exact ? reinterpret_cast<const void *>(&fir1_stream_kernel<true, true>)
+                   : reinterpret_cast<const void *>(&fir1_stream_kernel<false, true>);
+    } else {
+        fn = exact ? reinterpret_cast<const void *>(&fir1_stream_kernel<true, false>)
+                   : reinterpret_cast<const void *>(&fir1_stream_kernel<false, false>);
+    }
+    hipError_t e = ensure_dynamic_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    FrontParams pp = p;
+    void *args[] = {&pp, &ctl};
+    e = hipExtLaunchKernel(fn, dim3((uint32_t)grid), dim3(64), args, lds, stream, t0, t1, 0);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// sparse front-end output: zero what the previous run wrote
+// ---------------------------------------------------------------------------
+// With FrontParams::sparse the tuned 1-stage kernels store nothing for quiet
+// tiles; their words / infos must be zero when the run starts.  A tile whose
+// words are not all zero has a non-zero info (a level change inside it, or its
+// first bit set), so the previous run's infos tell which tiles to zero: one
+// pass over 4 B per tile (0.2 % of the capture's bytes).
+__global__ __launch_bounds__(256) void clear_tiles_kernel(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles,
+                                                          uint32_t tiles_per_cap, uint64_t words_per_cap,
+                                                          uint32_t words_per_tile) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+    for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < ntiles; t += stride) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(tile_info + t);       // tiles_per_cap is a multiple of 8
+        if ((q.x | q.y | q.z | q.w) == 0) continue;
+        const uint32_t info[4] = {q.x, q.y, q.z, q.w};
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (!info[k]) continue;
+            const uint64_t tt = t + k;
+            const uint64_t cap = tt / tiles_per_cap, tile = tt - cap * tiles_per_cap;
+            uint64_t *w = bits + cap * words_per_cap + tile * words_per_tile;
+            for (uint32_t i = 0; i < words_per_tile; i += 2) *reinterpret_cast<uint4 *>(w + i) = make_uint4(0, 0, 0, 0);
+        }
+        *reinterpret_cast<uint4 *>(tile_info + t) = make_uint4(0, 0, 0, 0);
+    }
+}
+
+hipError_t launch_clear_tiles(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles, uint32_t tiles_per_cap,
+                              uint64_t words_per_cap, uint32_t tile_bits, hipStream_t stream) {
+    if (ntiles == 0) return hipSuccess;
+    uint64_t blocks = (ntiles / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clear_tiles_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, tile_info, bits, ntiles,
+                       tiles_per_cap, words_per_cap, tile_bits / 64u);
+    return hipGetLastError();
 }
 
 hipError_t launch_unpack(const int16_t *iq, float *out, uint64_t n, hipStream_t stream) {

@@ -63,6 +63,31 @@ struct FrontParams {
                                 // (its first bit vs. the tile before NOT included)
                                 // | first bit << 30 | last bit << 31; [captures][tiles_per_cap]
     uint32_t tiles_per_cap;
+    uint32_t sparse;            // tuned 1-stage kernels: quiet tiles store nothing (their words / infos are zero
+                                // already: launch_clear_tiles zeroed what the run before wrote)
+};
+
+// Sparse front-end output: zero the words / infos of the tiles the previous run wrote (non-zero info).
+hipError_t launch_clear_tiles(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles, uint32_t tiles_per_cap,
+                              uint64_t words_per_cap, uint32_t tile_bits, hipStream_t stream);
+// does this shape run on a kernel that honours FrontParams::sparse?
+bool front_sparse_capable(const FrontParams &p);
+
+// ---- streaming (persistent) form of the tuned front end ------------------------------
+constexpr int kStreamGroup = 2;         // wave tiles per ticket (1024 outputs, 4 KiB of input)
+constexpr int kStreamHeads = 1024;      // ticket heads (head = workgroup % heads owns groups = head mod heads)
+constexpr int kStreamHeadStride = 16;   // dwords between heads (own 64-B lines: atomics execute at the memory side)
+constexpr int kMaxChunks = 256;
+
+struct StreamCtl {
+    uint32_t *heads;            // [kStreamHeads * kStreamHeadStride] ticket heads, zero at launch
+    uint32_t *done;             // [num_chunks] groups finished per chunk (zero at launch), or null
+    const uint32_t *chunk_end;  // [num_chunks] first group (global, capture-major) past each chunk
+    uint32_t num_chunks;
+    uint32_t num_caps;
+    uint32_t waves_per_cu;      // persistent single-wave workgroups per CU (0 = default)
+    uint32_t groups_per_cap;    // filled in by the launcher: tiles_per_cap / kStreamGroup
+    uint32_t num_heads;         // filled in by the launcher
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a kernel needs
@@ -71,6 +96,12 @@ hipError_t ensure_dynamic_lds(const void *func, size_t bytes);
 
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream,
                         hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// Streaming form (1 stage / decimation 1 / <= 256 taps only: front_streams()).  ctl.heads (and
+// ctl.done) must be zero when the kernel starts; write_through: bit words / tile infos are stored
+// past the L2 so that a kernel started while this one runs reads them (ctl.done tells when).
+bool front_streams(const FrontParams &p);
+hipError_t launch_front_stream(const FrontParams &p, StreamCtl ctl, bool exact, bool write_through,
+                               hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // 1024-ish output windows ("wave tiles") the tuned kernels split a capture into
 // (0 when the generic kernel serves this shape).
 uint64_t front_wave_tiles(const FrontParams &p);

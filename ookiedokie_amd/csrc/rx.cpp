@@ -34,6 +34,9 @@ namespace {
 constexpr uint32_t kIterBatch = 4;      // FSM fix-point rounds queued per host sync
 constexpr uint32_t kMaxIter = 1u << 16;
 constexpr uint64_t kHostMsgFirst = 2048;    // messages copied with the header
+// control block of the streaming front end: ticket heads | per-chunk counters | chunk ends
+constexpr size_t kCtlHeads = 0, kCtlDone = (size_t)kStreamHeads * kStreamHeadStride, kCtlChunkEnd = kCtlDone + kMaxChunks,
+                 kCtlWords = kCtlChunkEnd + kMaxChunks;
 
 struct ResultHeader {
     uint32_t changed[kIterBatch];
@@ -260,6 +263,13 @@ struct ookd_rx {
     bool count_quiet = false;
     DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics)
     DevBuf<uint32_t> d_tile_info;   // per wave tile edge counts written by the tuned front-end kernels
+    DevBuf<uint32_t> d_ctl;         // streaming front end: ticket heads | chunk counters | chunk ends
+    // sparse front-end output: extents of what the previous run may have written (zeroed by the next run)
+    bool sparse = false;
+    uint64_t dirty_tiles = 0, dirty_words_per_cap = 0;
+    uint32_t dirty_tiles_per_cap = 0;
+    bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
+    uint32_t stream_waves = 12;     // persistent front-end waves per CU
 
     // device (state machine)
     bool have_fsm = false;
@@ -343,6 +353,9 @@ struct ookd_rx {
         d_bits.release();
         d_fir.release();
         d_halo.release();
+        d_tile_info.release();
+        d_ctl.release();
+        d_quiet.release();
         d_blk_count.release();
         d_blk_offset.release();
         d_group_total.release();
@@ -421,6 +434,7 @@ struct ookd_rx {
             const uint32_t tile_bits = front_tile_bits(p);
             p.tiles_per_cap = tile_bits ? (uint32_t)(run_words * 64 / tile_bits) : 0;
         }
+        p.sparse = sparse ? 1u : 0u;
         return p;
     }
 
@@ -498,7 +512,26 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
-    if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
+    if (sparse) {
+        // quiet tiles store nothing: zero what the run before wrote, remember what this one may write
+        HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap,
+                                  front_tile_bits(fp), stream));
+        dirty_tiles = (uint64_t)run_caps * fp.tiles_per_cap;
+        dirty_tiles_per_cap = fp.tiles_per_cap;
+        dirty_words_per_cap = run_words;
+    }
+    if (!front_grid && front_streams(fp)) {
+        // persistent streaming form: capped residency, other contexts' kernels run beside it
+        HIPCHK(hipMemsetAsync(d_ctl.p, 0, sizeof(uint32_t) * kCtlChunkEnd, stream));
+        StreamCtl ctl{};
+        ctl.heads = d_ctl.p + kCtlHeads;
+        ctl.done = nullptr;
+        ctl.chunk_end = d_ctl.p + kCtlChunkEnd;
+        ctl.num_chunks = 0;
+        ctl.num_caps = run_caps;
+        ctl.waves_per_cu = stream_waves;
+        HIPCHK(launch_front_stream(fp, ctl, exact, false, stream, ev[0], ev[1]));
+    } else if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
         // wait + launch + publish under the lock: the event must be on its way before another
         // context may wait for it
         std::lock_guard<std::mutex> lock(g_gate.m);
@@ -979,6 +1012,11 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rc |= rx->d_halo.alloc(2 * (rx->halo_needed + 4));
     rc |= rx->d_blk_count.alloc(caps * blocks + 1);
     rc |= rx->d_tile_info.alloc(caps * blocks * 16 + 16);       // smallest wave tile: 256 bits
+    rc |= rx->d_ctl.alloc(kCtlWords);
+    // the streaming (persistent) form is experimental: it caps the front end's residency, but is
+    // slower than the hardware-dispatched grid; OOKD_FRONT_STREAM=1 selects it
+    rx->front_grid = (cfg->flags & OOKD_RX_FRONT_GRID) != 0 || !getenv("OOKD_FRONT_STREAM");
+    if (const char *w = getenv("OOKD_STREAM_WAVES")) rx->stream_waves = (uint32_t)std::max(1, atoi(w));
     rc |= rx->d_blk_offset.alloc(caps * blocks + 1);
     rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
@@ -1083,6 +1121,19 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         }
     }
     if (rc != OOKD_OK) return nullptr;
+    {
+        // sparse front-end output (1-stage kernels with the quiet shortcut, no float dump): the bit
+        // words and tile infos start out zero and every run zeroes what the run before wrote
+        FrontParams probe = rx->front_params(nullptr, 0);
+        probe.n_out = rx->max_n_out;
+        rx->sparse = front_sparse_capable(probe) && !getenv("OOKD_DENSE_BITS");
+        if (rx->sparse &&
+            (hipMemset(rx->d_bits.p, 0, rx->d_bits.n * sizeof(uint64_t)) != hipSuccess ||
+             hipMemset(rx->d_tile_info.p, 0, rx->d_tile_info.n * sizeof(uint32_t)) != hipSuccess)) {
+            set_error("hipMemset of the bit words failed");
+            return nullptr;
+        }
+    }
     if (hipHostMalloc(reinterpret_cast<void **>(&rx->h_hdr), sizeof(ResultHeader)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&rx->h_msgs), rx->msg_capacity * sizeof(MsgDev)) != hipSuccess) {
         set_error("hipHostMalloc failed");
