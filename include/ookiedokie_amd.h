@@ -172,7 +172,9 @@ enum {
     /* Front end: launch one workgroup per wave tile (the round-1 form) instead
      * of the persistent streaming grid that pulls batches of tiles from ticket
      * heads (identical bits; exists so the tests can run both). */
-    OOKD_RX_FRONT_GRID = 1u << 6
+    OOKD_RX_FRONT_GRID = 1u << 6,
+    /* Never pipeline a long capture in chunks (see pipeline_chunk_samples). */
+    OOKD_RX_NO_PIPELINE = 1u << 7
 };
 
 typedef struct ookd_rx_config {
@@ -187,6 +189,12 @@ typedef struct ookd_rx_config {
     uint32_t message_slots;         /* per segment, 0 = default               */
     uint64_t message_capacity;      /* messages per run, 0 = default (65536)  */
     void *stream;                   /* hipStream_t to launch on, NULL = own   */
+    uint64_t pipeline_chunk_samples;/* non-zero: single-capture runs at least twice this long are
+                                       pipelined in chunks of about this many input samples: the front
+                                       end of chunk c+1 is queued beside the edges / state machine of
+                                       chunk c, the state machine's state carried from chunk to chunk in
+                                       device memory (results identical).  0 = never (the default: on
+                                       this runtime the chunked run is slower)          */
 } ookd_rx_config;
 
 typedef struct ookd_message {
@@ -229,6 +237,8 @@ typedef struct ookd_rx_stats {
                                        shortcut (only with OOKD_RX_COUNT_QUIET) */
     uint64_t total_waves;           /* 1024-output windows of the run (1-stage
                                        decimation-1 front end; else 0)        */
+    uint32_t pipeline_chunks;       /* chunks the run was pipelined in (0 = not pipelined) */
+    uint32_t reserved;
 } ookd_rx_stats;
 
 ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,

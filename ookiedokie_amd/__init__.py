@@ -42,6 +42,7 @@ RX_NO_QUIET_SKIP = 8
 RX_COUNT_QUIET = 16
 RX_SCAN_SIMS = 32
 RX_FRONT_GRID = 64
+RX_NO_PIPELINE = 128
 DEFAULT_THRESHOLD = 0.1                 # ookiedokie_cfg.c:27
 DEFAULT_RATE = 3000000                  # ookiedokie_cfg.c:32
 DEFAULT_SAMPLES_PER_BUF = 8192          # ookiedokie_cfg.c:34
@@ -81,6 +82,7 @@ class RxConfig(C.Structure):
         ("max_captures", C.c_uint32), ("edge_capacity", C.c_uint64),
         ("segment_buffers", C.c_uint32), ("message_slots", C.c_uint32),
         ("message_capacity", C.c_uint64), ("stream", C.c_void_p),
+        ("pipeline_chunk_samples", C.c_uint64),
     ]
 
 
@@ -107,6 +109,7 @@ class RxStats(C.Structure):
         ("fsm_path", C.c_uint32), ("fsm_fallback_reason", C.c_uint32),
         ("fir_kernel_ms", C.c_float), ("total_device_ms", C.c_float),
         ("quiet_waves", C.c_uint64), ("total_waves", C.c_uint64),
+        ("pipeline_chunks", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -511,13 +514,13 @@ class Receiver:
                  edge_capacity: int = 0, segment_buffers: int = 0, message_slots: int = 0,
                  message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
                  quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False,
-                 front_grid: bool = False):
+                 front_grid: bool = False, pipeline: bool = True, pipeline_chunk_samples: int = 0):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
                      | (RX_FSM_ROUNDS if fsm_rounds else 0) | (0 if quiet_skip else RX_NO_QUIET_SKIP)
                      | (RX_COUNT_QUIET if count_quiet else 0) | (RX_SCAN_SIMS if scan_sims else 0)
-                     | (RX_FRONT_GRID if front_grid else 0))
+                     | (RX_FRONT_GRID if front_grid else 0) | (0 if pipeline else RX_NO_PIPELINE))
         cfg.threshold = threshold
         cfg.samples_per_buffer = samples_per_buffer
         cfg.max_samples = max_samples
@@ -527,6 +530,7 @@ class Receiver:
         cfg.message_slots = message_slots
         cfg.message_capacity = message_capacity
         cfg.stream = stream
+        cfg.pipeline_chunk_samples = pipeline_chunk_samples
         self._filter, self._device = filt, device
         self.payload_bytes = device.payload_bytes if device else 0
         self.total_decimation = filt.total_decimation if filt else 1

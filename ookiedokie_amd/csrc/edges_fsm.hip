@@ -41,9 +41,11 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) {
 // first line does for sample 0, ookiedokie.c:150-153).
 // Changes at or beyond n_out do not exist (the words past the capture are
 // zero padding, not samples).
-__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w, uint64_t n_out) {
+// has_prev: the words continue in front of `words` (a chunk of a pipelined run): the level before
+// its first sample is the last bit of the chunk before, not 0.
+__device__ __forceinline__ uint64_t change_word(const uint64_t *words, uint64_t w, uint64_t n_out, uint32_t has_prev = 0) {
     const uint64_t cur = words[w];
-    const uint64_t prev_top = (w == 0) ? 0ull : (words[w - 1] >> 63);
+    const uint64_t prev_top = (w == 0 && !has_prev) ? 0ull : (*(words + w - 1) >> 63);
     const uint64_t e = cur ^ ((cur << 1) | prev_top);
     const uint64_t base = w * 64;
     if (base + 64 <= n_out) return e;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void edge_count_kernel(const EdgeParams p) {
     const uint32_t cap = wave / p.blocks_per_cap;
     const uint32_t blk = wave % p.blocks_per_cap;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
-    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id(), p.n_out);
+    const uint64_t e = change_word(words, (uint64_t)blk * kBlockWords + lane_id(), p.n_out, p.has_prev);
     uint32_t c = (uint32_t)__popcll(e);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
             const uint32_t tile_bits = (uint32_t)(kBlockWords * 64) / tpb;
             const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
             const uint32_t t0 = blk * tpb;
-            uint32_t prev_last = t0 ? ti[t0 - 1] >> 31 : 0u;
+            uint32_t prev_last = (t0 || p.has_prev) ? *(ti + t0 - 1) >> 31 : 0u;
             uint32_t c = 0;
             // a block's tiles are 4, 8 or 16 consecutive words: fetch them 16 B at a time
             for (uint32_t t4 = 0; t4 < tpb; t4 += 4) {
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(1024) void edge_scan_groups_kernel(const EdgeParams
     if (tid == 1023) {
         p.blk_offset[n] = total;
         if ((uint64_t)total > p.edge_capacity) *p.overflow = 1;
+        if (p.total_acc) atomicAdd(p.total_acc, total);
     }
 }
 
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
         const uint32_t blk = b % p.blocks_per_cap;
         const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
         const uint64_t w = (uint64_t)blk * kBlockWords + lane;
-        uint64_t e = change_word(words, w, p.n_out);
+        uint64_t e = change_word(words, w, p.n_out, p.has_prev);
         const uint32_t c = (uint32_t)__popcll(e);
         uint32_t inc = c;
 #pragma unroll
@@ -204,6 +207,54 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
             ++at;
             e &= e - 1;
         }
+    }
+}
+
+// The same behind the tuned front-end kernels, which leave a count of level changes per wave
+// tile: ONE LANE per 4096-bit block.  The lanes of a wave read their blocks' offsets / counts
+// and tile infos coalesced, add the group base, and only a block's tiles that hold a change have
+// their words read (8 or 16 words) -- a capture is mostly constant level, so that is a few
+// percent of the bit words, where edge_write_kernel reads every word of every block that
+// holds an edge.  Positions come out ascending: tiles in order, words in order, bits in order.
+__global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams p) {
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
+    if (b >= total_blocks) return;
+    const uint32_t off = p.blk_offset[b] + p.group_total[b / kScanGroup];
+    p.blk_offset[b] = off;
+    if (p.blk_count[b] == 0) return;
+    const uint32_t cap = b / p.blocks_per_cap, blk = b - cap * p.blocks_per_cap;
+    const uint32_t tpb = p.tiles_per_block;
+    const uint32_t words_per_tile = (uint32_t)kBlockWords / tpb;
+    const uint32_t tile_bits = words_per_tile * 64u;
+    const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
+    const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
+    const uint32_t t0 = blk * tpb;
+    uint32_t prev_last = (t0 || p.has_prev) ? *(ti + t0 - 1) >> 31 : 0u;
+    uint64_t at = off;
+    for (uint32_t t = 0; t < tpb; ++t) {
+        const bool live = (uint64_t)(t0 + t) * tile_bits < p.n_out;
+        const uint32_t info = live ? ti[t0 + t] : 0u;
+        const uint32_t c = live ? (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+        if (c) {
+            const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
+            uint64_t carry = prev_last;
+            for (uint32_t i = 0; i < words_per_tile; ++i) {
+                const uint64_t cur = words[w0 + i];
+                uint64_t e = cur ^ ((cur << 1) | carry);
+                carry = cur >> 63;
+                const uint64_t base = (w0 + i) * 64;
+                if (base + 64 > p.n_out) e &= base >= p.n_out ? 0ull : ((1ull << (p.n_out - base)) - 1ull);
+                while (e) {
+                    const int bit = __ffsll((long long)e) - 1;
+                    if (at < p.edge_capacity) p.edges[at] = base + (uint64_t)bit;
+                    ++at;
+                    e &= e - 1;
+                }
+            }
+        }
+        prev_last = live ? info >> 31 : prev_last;
     }
 }
 
@@ -848,8 +899,12 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
     if (!p.tile_info) hipLaunchKernelGGL(edge_count_kernel, dim3(wgs), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
-    const uint32_t write_waves = (total_blocks + kWriteSpan - 1) / kWriteSpan;
-    hipLaunchKernelGGL(edge_write_kernel, dim3((write_waves + 3) / 4), dim3(256), 0, stream, p);
+    if (p.tile_info) {
+        hipLaunchKernelGGL(edge_write_tiles_kernel, dim3((total_blocks + 255) / 256), dim3(256), 0, stream, p);
+    } else {
+        const uint32_t write_waves = (total_blocks + kWriteSpan - 1) / kWriteSpan;
+        hipLaunchKernelGGL(edge_write_kernel, dim3((write_waves + 3) / 4), dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
 

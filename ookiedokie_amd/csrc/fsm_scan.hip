@@ -79,7 +79,9 @@ struct LTab {
     uint32_t max_bits, S, NB1, D;       // NB1 = max_bits + 2 bit-count values; D = S*NB1 + 3 + stuck codes
     uint32_t spb, decim;
     uint32_t NS, nstuck_rows;           // stuck codes: S*NB1 + 3 + (d-1)*NS + index in stuck_src
-    uint32_t depth, pad_;               // d = 1 .. depth <= kStuckDepth
+    uint32_t depth;                     // d = 1 .. depth <= kStuckDepth
+    uint32_t lvl0;                      // level in front of the capture's first sample: 0, or (chunk of a pipelined run,
+                                        // set by the kernels) the last bit of the chunk before; leaf i runs at lvl0 ^ (i & 1)
     uint16_t stuck_src[kMaxStuck];      // ascending: the normal codes that can get stuck
     uint8_t stuck_row[kMaxStuckRows];   // row | level << 7: span-table rows with a stuck result, met at that level
 };
@@ -330,11 +332,11 @@ struct Span {                   // the samples a leaf covers
 };
 
 // leaf i (1 <= i < ne): samples e[i-1]+1 .. e[i]
-__device__ __forceinline__ Span span_of(const uint64_t *edges, uint64_t i) {
+__device__ __forceinline__ Span span_of(const LTab &T, const uint64_t *edges, uint64_t i) {
     Span s;
     s.pos0 = edges[i - 1] + 1;
     s.n = edges[i] - edges[i - 1] - 1;
-    s.L = (uint32_t)(i & 1ull);         // level after edge i-1
+    s.L = (uint32_t)(i & 1ull) ^ T.lvl0;        // level after edge i-1
     s.has_edge = true;
     s.prefix = 0;
     return s;
@@ -474,6 +476,12 @@ struct ScanParams {
     uint64_t err_capacity;
     FsmStateDev first;
     int have_first;
+    // chunked (pipelined) runs: one launch of the scan per chunk of ONE capture, in stream order
+    const SegState *first_dev;  // incoming state in device memory (the chunk before's final_state), or null
+    uint32_t has_prev;          // the bit words continue in front of f.bits (chunk > 0): lvl0 = bits[-1] >> 63
+    uint64_t pos_origin;        // the chunk's first decimated sample: added to message / error positions
+    const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device), or null = 0
+    const uint32_t *edge_overflow;      // the edge stage's overflow flag: the scan refuses such a run
     SegState *final_state;
     uint32_t *fallback;
     uint32_t total_blocks_cap;
@@ -617,7 +625,7 @@ __device__ __noinline__ uint32_t stuck_step(const LTab &T, const StuckCtx &c, ui
     if (n > 0xfffffff0ull) return code_poison(T);
     const uint32_t cur = src / NB1, nb = src - cur * NB1;
     const uint32_t pk = lt_lookup(c.lt_off, c.lt_n0, c.lt_pk, 2 * cur + (nb >= T.max_bits ? 1u : 0u),
-                                  (uint32_t)(i & 1ull), (uint32_t)n);
+                                  (uint32_t)(i & 1ull) ^ T.lvl0, (uint32_t)n);
     if (pk & kPkAbsolute) return pk & 0xffffu;
     if (pk & kPkRelative) {
         const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
@@ -629,7 +637,7 @@ __device__ __noinline__ uint32_t stuck_step(const LTab &T, const StuckCtx &c, ui
 
 // the span of leaf i as the simulator has to run it when the leaf is entered in `code`
 __device__ __forceinline__ Span span_entered(const LTab &T, const uint64_t *edges, uint64_t i, uint32_t &code) {
-    Span sp = span_of(edges, i);
+    Span sp = span_of(T, edges, i);
     if (code >= T.S * T.NB1 + 3) {
         uint32_t d, src;
         stuck_decode(T, code, d, src);
@@ -747,7 +755,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         for (uint32_t task = threadIdx.x; task < nu * S; task += blockDim.x) {
             const uint32_t k = task / nu, up = task - k * nu;
             const uint32_t l = uniq[1 + up];
-            const Span sp = span_of(edges, first + l);
+            const Span sp = span_of(T, edges, first + l);
             uint32_t p0, p1;
             if (sp.n <= 0xfffffff0ull) {
                 p0 = lt_lookup(lt_off, lt_n0, lt_pk, 2 * k, sp.L, (uint32_t)sp.n);
@@ -769,7 +777,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         for (uint32_t task = threadIdx.x; task < 2 * count; task += blockDim.x) {
             const uint32_t kk = task / count, lp = task - kk * count;
             const uint32_t l = parity_order(lp, count);
-            const Span sp = span_of(edges, first + l);
+            const Span sp = span_of(T, edges, first + l);
             const uint64_t end_const = sp.pos0 + sp.n, last = end_const + 1;
             const uint64_t rs = resume[l];
             uint32_t out;
@@ -805,7 +813,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
             const uint32_t t2 = task - nnorm;
             const uint32_t k = t2 / count, lp = t2 - k * count;
             const uint32_t l = parity_order(lp, count);
-            const bool alive = run_leaf(T, S * NB1 + k, span_of(edges, first + l), resume[l], f, a);
+            const bool alive = run_leaf(T, S * NB1 + k, span_of(T, edges, first + l), resume[l], f, a);
             res[l * nsim + 2 * S + k] = pack_absolute(encode_post(T, f, a, alive), NB1);
             continue;
         }
@@ -813,7 +821,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         const uint32_t k = pair / nu, up = pair - k * nu;
         const uint32_t l = uniq[1 + up];
         const uint32_t nb0 = cls ? max_bits : 0u;
-        const bool alive = run_leaf(T, k * NB1 + nb0, span_of(edges, first + l), resume[l], f, a);
+        const bool alive = run_leaf(T, k * NB1 + nb0, span_of(T, edges, first + l), resume[l], f, a);
         res[l * nsim + 2 * k + cls] = pack_normal(T, f, a, alive, nb0, cls);
     }
     }
@@ -842,7 +850,7 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
         // (only rows of states that can be met at the leaf's level count: stuck_row = row | level << 7)
         for (uint32_t e = threadIdx.x; e < count * T.nstuck_rows; e += blockDim.x) {
             const uint32_t l = e / T.nstuck_rows, rl = T.stuck_row[e - l * T.nstuck_rows];
-            if ((rl >> 7) != (uint32_t)((first + l) & 1ull)) continue;
+            if ((rl >> 7) != ((uint32_t)((first + l) & 1ull) ^ T.lvl0)) continue;
             if (res[l * nsim + (rl & 127u)] & kPkStuck) atomicOr(&cap[(l + kStuckDepth) >> 5], 1u << ((l + kStuckDepth) & 31u));
         }
         for (uint32_t t = threadIdx.x; t < T.depth * T.nstuck_rows; t += blockDim.x) {
@@ -850,10 +858,10 @@ __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first,
             const uint32_t r = rl & 127u;
             if (first < (uint64_t)j + 1) continue;                  // leaf first - j >= 1
             const uint64_t i = first - j;
-            if ((rl >> 7) != (uint32_t)(i & 1ull)) continue;
+            if ((rl >> 7) != ((uint32_t)(i & 1ull) ^ T.lvl0)) continue;
             const uint64_t n = edges[i] - edges[i - 1] - 1;
             if (n > 0xfffffff0ull) continue;
-            if (lt_lookup(lt_off, lt_n0, lt_pk, r, (uint32_t)(i & 1ull), (uint32_t)n) & kPkStuck) {
+            if (lt_lookup(lt_off, lt_n0, lt_pk, r, (uint32_t)(i & 1ull) ^ T.lvl0, (uint32_t)n) & kPkStuck) {
                 atomicOr(&cap[(kStuckDepth - j) >> 5], 1u << ((kStuckDepth - j) & 31u));
             }
         }
@@ -900,7 +908,7 @@ __device__ void block_expand(const LTab &T, const StuckCtx &sc, const uint64_t *
                 // exact per-count simulation (rare)
                 PSim f;
                 Acc a;
-                const bool alive = run_leaf(T, e, span_of(edges, first + l), resume[l], f, a);
+                const bool alive = run_leaf(T, e, span_of(T, edges, first + l), resume[l], f, a);
                 out = encode_post(T, f, a, alive);
             }
             tab[l * SNB + e] = (uint16_t)out;
@@ -930,18 +938,25 @@ __device__ __forceinline__ void locate_block(const ScanParams &sp, uint32_t gb, 
     lb = gb - sp.cap_block_off[lo];
 }
 
+// the concrete incoming state: reset, the host's (shards), or the chunk before's (pipelined runs)
+__device__ __forceinline__ FsmStateDev scan_first(const ScanParams &sp) {
+    if (sp.first_dev) return sp.first_dev->st;
+    return sp.first;            // zeros without have_first
+}
+
 // A capture's first span (samples 0 .. first edge; the whole capture when it
 // has no edge) from the concrete incoming state.
 __device__ __forceinline__ bool first_leaf(const LTab &T, const ScanParams &sp, const uint64_t *edges, uint64_t ne, PSim &f,
                            Acc &a) {
-    f.cur = sp.have_first ? sp.first.cur : 0u;
-    f.nbits = sp.have_first ? sp.first.nbits : 0u;
-    f.prev = sp.have_first ? sp.first.prev : 0u;
-    const uint64_t k64 = sp.have_first ? sp.first.k : 0ull;
+    const FsmStateDev fs = scan_first(sp);
+    f.cur = sp.have_first ? fs.cur : 0u;
+    f.nbits = sp.have_first ? fs.nbits : 0u;
+    f.prev = sp.have_first ? fs.prev : 0u;
+    const uint64_t k64 = sp.have_first ? fs.k : 0ull;
     f.k = k64 > kSat ? kSat : (uint32_t)k64;
     acc_init(a);
     const uint64_t n = ne ? edges[0] : sp.f.n_out;
-    return sim_span(T, f, a, 0, 0u, n, ne != 0);
+    return sim_span(T, f, a, 0, T.lvl0, n, ne != 0);
 }
 
 __device__ __forceinline__ void write_event(LeafEvDev &ev, const Acc &a, const PSim &f, bool alive) {
@@ -1028,7 +1043,7 @@ __device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const StuckC
     if (pk & kPkStuck) return stuck_enter(T, sc, s);
     PSim f;                     // row depends on the exact bit count (rare): simulate
     Acc a;
-    const bool alive = run_leaf(T, s, span_of(edges, first + l), resume[l], f, a);
+    const bool alive = run_leaf(T, s, span_of(T, edges, first + l), resume[l], f, a);
     return encode_post(T, f, a, alive);
 }
 
@@ -1064,7 +1079,7 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
             l0[j] = c * kChunk;
             l1[j] = item < nitem ? min((c + 1) * kChunk, count) : l0[j];
             // a code that is never met at the level of the chunk's first leaf stays poison
-            if (!((rv >> 14) & (1u << ((first + l0[j]) & 1ull)))) l1[j] = l0[j], st[j] = SNB + 2;
+            if (!((rv >> 14) & (1u << (((first + l0[j]) & 1ull) ^ T.lvl0)))) l1[j] = l0[j], st[j] = SNB + 2;
         }
         uint32_t at[kIlp];              // leaf (relative to l0) in front of which the chain got stuck
 #pragma unroll
@@ -1154,6 +1169,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
         sp.fin_off[nc] = tot2;
         sp.cap_group_off[nc] = tot3;
         if (tot > sp.total_blocks_cap || tot2 > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
+        // more level changes than the edge list holds: its tail was never written and the buffers
+        // sized by the capacity would be overrun -- no scan (the host reports OOKD_ERR_CAPACITY)
+        if (sp.edge_overflow && *sp.edge_overflow) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
     }
 }
 
@@ -1166,6 +1184,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ uint32_t s_cap[kCapWords];
     __shared__ uint32_t s_lt[kLtLdsWords];
     copy_ltab(T, sp.ltab);
+    __syncthreads();
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
@@ -1335,6 +1355,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint16_t cin[32];
     copy_ltab(T, sp.ltab);
     __syncthreads();
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
+    __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
     const BlockLds b = carve(LB, D, T.S * T.NB1);
@@ -1447,7 +1469,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 tail.prefix = 0;
                 tail.pos0 = pos0;
                 tail.n = sp.f.n_out > pos0 ? sp.f.n_out - pos0 : 0;
-                tail.L = (uint32_t)(ne & 1ull);
+                tail.L = (uint32_t)(ne & 1ull) ^ T.lvl0;
                 tail.has_edge = false;
                 if (in > code_poison(T)) {              // entered stuck: run it from where the state was normal
                     uint32_t d, src;
@@ -1658,8 +1680,10 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             if (last) atomicMax(&s_acc[3], last);
         }
         __syncthreads();
-        const uint32_t nb0 = sp.have_first ? min(sp.first.nbits, max_bits + 1) : 0u;
+        const FsmStateDev fs = scan_first(sp);
+        const uint32_t nb0 = sp.have_first ? min(fs.nbits, max_bits + 1) : 0u;
         const uint32_t a_before = nb0 + s_acc[0], o_before = s_acc[1], e_before = s_acc[2];
+        const uint64_t base_m = sp.totals_in ? sp.totals_in[0] : 0ull, base_e = sp.totals_in ? sp.totals_in[1] : 0ull;
         const uint32_t jr = s_acc[3];           // block jr-1 holds the latest reset before this block
         __syncthreads();
         uint32_t epoch_in = 0;
@@ -1680,8 +1704,8 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
         if (tid == 0) {
             if (last_of_cap && (uint64_t)(a_before + L.a_tot) > 2 * (ne + 1) + 512) atomicOr(sp.fallback, (uint32_t)kFbPool);
             if (g + 1 == total) {
-                sp.f.totals[0] = (uint64_t)o_before + L.o_tot;
-                sp.f.totals[1] = (uint64_t)e_before + L.e_tot;
+                sp.f.totals[0] = base_m + o_before + L.o_tot;
+                sp.f.totals[1] = base_e + e_before + L.e_tot;
             }
         }
         const uint64_t pool0 = pool_start(e0, cap);
@@ -1690,25 +1714,32 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             continue;
         }
         uint8_t *vals = sp.app_vals + pool0;
-        if (fb == 0 && tid < nb0) vals[tid] = (uint8_t)((sp.first.data[tid >> 6] >> (tid & 63)) & 1ull);
+        if (fb == 0 && tid < nb0) vals[tid] = (uint8_t)((fs.data[tid >> 6] >> (tid & 63)) & 1ull);
         if (fb == 0 && tid == 0 && nb0 > (uint32_t)kFinBlock) atomicOr(sp.fallback, (uint32_t)kFbPool);
         if (!L.have) continue;
         const uint32_t ai = a_before + L.a_in;
         const uint32_t epoch = L.r_in ? a_before + L.r_in - 1 : epoch_in;
-        for (uint32_t j = 0; j < L.ev.napp && j < 32; ++j) vals[ai + j] = (uint8_t)((L.ev.appvals >> j) & 1u);
+        // (the pool check above runs in the capture's last block only, after the earlier ones have
+        //  written: a leaf that would write past its capture's pool stores nothing and refuses here)
+        const uint64_t pool_len = 2 * (ne + 1) + 512;
+        if ((uint64_t)ai + L.ev.napp > pool_len) {
+            atomicOr(sp.fallback, (uint32_t)kFbPool);
+        } else {
+            for (uint32_t j = 0; j < L.ev.napp && j < 32; ++j) vals[ai + j] = (uint8_t)((L.ev.appvals >> j) & 1u);
+        }
         if (L.ev.nerr) {
-            const uint64_t slot = (uint64_t)e_before + L.e_in;
-            if (slot < sp.err_capacity) sp.errs[slot] = L.ev.err_pos;
+            const uint64_t slot = base_e + e_before + L.e_in;
+            if (slot < sp.err_capacity) sp.errs[slot] = L.ev.err_pos + sp.pos_origin;
         }
         for (uint32_t j = 0; j < L.ev.nout && j < 2; ++j) {
             const uint32_t ep = L.ev.out_rb[j] != 0xffu ? ai + L.ev.out_rb[j] : epoch;
             const uint32_t have = ai + L.ev.out_ab[j] - ep;
-            const uint64_t slot = (uint64_t)o_before + L.o_in + j;
+            const uint64_t slot = base_m + o_before + L.o_in + j;
             if (slot < sp.f.msg_capacity) {
                 MsgDev mm;
                 mm.capture = cap;
                 mm.reserved = 0;
-                mm.sample = L.ev.out_pos[j];
+                mm.sample = L.ev.out_pos[j] + sp.pos_origin;
                 mm.payload[0] = (uint64_t)ep | ((uint64_t)have << 32);     // resolved by fin_msg_kernel
                 mm.payload[1] = mm.payload[2] = mm.payload[3] = 0;
                 sp.f.msgs[slot] = mm;
@@ -1752,8 +1783,10 @@ __global__ __launch_bounds__(256) void fin_msg_kernel(ScanParams sp, PublishPara
     const uint64_t nmsg = refused ? 0 : min((uint64_t)sp.f.totals[0], sp.f.msg_capacity);
     const uint64_t nitems = refused ? 0 : nmsg + sp.f.num_captures;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // (a chunk of a pipelined run resolves its own messages: those behind the chunks before's)
+    const uint64_t m0 = refused ? 0 : min(sp.totals_in ? sp.totals_in[0] : 0ull, nmsg);
     MsgDev *h_msgs = reinterpret_cast<MsgDev *>(pp.h_msgs);
-    for (uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nitems; m += stride) {
+    for (uint64_t m = m0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m < nitems; m += stride) {
         if (m < nmsg) {
             MsgDev mm = sp.f.msgs[m];
             uint64_t e0;
@@ -1857,6 +1890,7 @@ void fill_ltab_host(LTab &T, const FsmTablesDev &g, uint32_t spb, uint32_t decim
     T.NS = 0;
     T.nstuck_rows = 0;
     T.depth = 0;
+    T.lvl0 = 0;
 }
 
 // adds the stuck codes (found by build_leaf_tables) to the domain
@@ -2145,8 +2179,13 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.app_capacity = a.app_capacity;
     sp.errs = a.errs;
     sp.err_capacity = a.err_capacity;
-    sp.have_first = a.first ? 1 : 0;
+    sp.have_first = (a.first || a.first_dev) ? 1 : 0;
     if (a.first) sp.first = *a.first;
+    sp.first_dev = a.first_dev;
+    sp.has_prev = a.first_dev ? 1u : 0u;
+    sp.pos_origin = a.pos_origin;
+    sp.totals_in = a.totals_in;
+    sp.edge_overflow = a.edge_overflow;
     sp.final_state = a.final_state;
     sp.fallback = a.fallback;
     sp.total_blocks_cap = a.total_blocks_cap;
@@ -2162,7 +2201,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.lt_n0 = a.lt_n0;
     sp.lt_pk = a.lt_pk;
     sp.ltab = a.ltab;
-    // with a concrete incoming state (shards) the first span may leave the closure: no pruning
+    // with a concrete incoming state from outside (shards) the first span may leave the closure: no
+    // pruning.  The state a chunk of a pipelined run hands to the next is one the whole capture's
+    // run passes through: the code behind the chunk's first edge lies in the closure.
     sp.reach = a.first ? nullptr : a.reach;
     sp.nreach = a.first ? 0 : a.nreach;
     sp.nreach_base = a.first ? 0 : a.nreach_base;

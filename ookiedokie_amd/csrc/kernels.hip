@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
     const uint32_t tid = threadIdx.x & 63u;             // lane: every wavefront works alone
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = ((uint64_t)blockIdx.x * kFirWgWaves + wave) * kTile;
+    const uint64_t t0 = (((uint64_t)blockIdx.x + p.tile_base) * kFirWgWaves + wave) * kTile;
     const uint32_t Tp = p.stage[0].ntaps_pad;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
     float2 *lds = reinterpret_cast<float2 *>(smem_raw) + wave * fir1_wave_slots<R>(Tp);
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         const int L = p.quiet_lsb;
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
-            // sparse output: the tile's words and info are zero already (launch_clear_tiles)
+            // sparse output: the tile's words and info are zero already (launch_clear_tiles; a check of the
+            // tile's old info in here instead -- 4 B per tile -- cost the kernel 10 %)
             if (!p.sparse) {
                 if (tid < kTile / 64) words[(t0 >> 6) + tid] = 0;
                 if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = 0;
@@ -507,9 +508,10 @@ __global__ __launch_bounds__(64) void fir1_stream_kernel(const FrontParams p, co
         chunk_count = 0;
     };
 
-    uint32_t g = resolve_ticket(issue_ticket());
+    const bool strided = ctl.static_stride != 0;        // experiment: no tickets, group = workgroup + k * grid
+    uint32_t g = strided ? (blockIdx.x < ngroups ? blockIdx.x : kNoGroup) : resolve_ticket(issue_ticket());
     while (g != kNoGroup) {
-        const uint32_t t_next = issue_ticket();         // returns while the group's loads are waited for
+        const uint32_t t_next = strided ? 0u : issue_ticket();         // returns while the group's loads are waited for
         const uint32_t cap = g / ctl.groups_per_cap;
         const uint64_t g0 = (uint64_t)(g - cap * ctl.groups_per_cap) * kGroupOut;
         const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
@@ -526,6 +528,7 @@ __global__ __launch_bounds__(64) void fir1_stream_kernel(const FrontParams p, co
             }
             q.hal = ld_nt(s4 - 64);     // (lanes below hal0 fetch samples further back: never used)
         }
+
         uint32_t quiet_mask = 0, info_vec = 0;
         bool info_vec_any = false;
 #pragma unroll
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(64) void fir1_stream_kernel(const FrontParams p, co
             }
             chunk_count++;
         }
-        g = resolve_ticket(t_next);
+        if (strided) g = (uint64_t)g + gridDim.x < ngroups ? g + gridDim.x : kNoGroup;
+        else g = resolve_ticket(t_next);
     }
     flush_chunk();
 }
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
     const uint32_t tid = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t cap = blockIdx.y;
-    const uint64_t J0 = ((uint64_t)blockIdx.x * kFir2Waves + wave) * G::F;     // first final output
+    const uint64_t J0 = (((uint64_t)blockIdx.x + p.tile_base) * kFir2Waves + wave) * G::F;     // first final output
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
     uint32_t *lds0 = reinterpret_cast<uint32_t *>(smem_raw + wave * G::wave_bytes);    // raw I,Q pairs
     float2 *lds1 = reinterpret_cast<float2 *>(lds0 + G::slots0);
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(const FrontParams p, u
 __global__ __launch_bounds__(64) void nofir_bits_kernel(const FrontParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t cap = blockIdx.y;
-    const uint64_t t0 = (uint64_t)blockIdx.x * kWaveTile;
+    const uint64_t t0 = ((uint64_t)blockIdx.x + p.tile_base) * kWaveTile;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride;
     uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     float2 *fout = p.fir_out ? reinterpret_cast<float2 *>(p.fir_out) + (uint64_t)cap * p.n_out : nullptr;
@@ -1238,54 +1242,59 @@ uint32_t front_tile_bits(const FrontParams &p) {
 // packets in front of and behind the dominant kernel, and their difference is the kernel's
 // duration as a profiler sees it.
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream,
-                        hipEvent_t t0, hipEvent_t t1) {
+                        hipEvent_t t0, hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count) {
     if (p.n_out == 0) {
         if (t0 && hipEventRecord(t0, stream) != hipSuccess) return hipGetLastError();
         if (t1 && hipEventRecord(t1, stream) != hipSuccess) return hipGetLastError();
         return hipSuccess;
     }
+    // [tile_begin, tile_begin + tile_count) of the capture's wave tiles (tuned kernels only), default: all
+    auto range = [&](uint64_t all, uint64_t &grid, FrontParams &pp) {
+        const uint64_t b = tile_begin < all ? tile_begin : all;
+        grid = tile_count < all - b ? tile_count : all - b;
+        pp.tile_base = (uint32_t)b;
+    };
+    FrontParams pp = p;
+    void *args[] = {&pp};
+    uint64_t grid = 0;
     if (p.num_stages == 0) {
         // whole 4096-sample blocks, so every bit word of the capture is written
-        const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * kFirWaves;
-        hipExtLaunchKernelGGL(nofir_bits_kernel, dim3((uint32_t)tiles, num_captures), dim3(64), 0, stream, t0, t1, 0,
-                              p);
-        return hipGetLastError();
+        range((p.n_out + kFirTile - 1) / kFirTile * kFirWaves, grid, pp);
+        if (grid == 0) return hipSuccess;
+        const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&nofir_bits_kernel),
+                                                dim3((uint32_t)grid, num_captures), dim3(64), args, 0, stream, t0, t1, 0);
+        return e != hipSuccess ? e : hipGetLastError();
     }
     if (use_fir1(p)) {
         const size_t lds = fir1_lds_bytes(p);
-        {
-            // whole 4096-output blocks, so every bit word of the capture is written
-            const int R = fir1_R(p);
-            const uint64_t tiles = (p.n_out + kFirTile - 1) / kFirTile * (kFirTile / (64 * R) / kFirWgWaves);
-            dim3 grid((uint32_t)tiles, num_captures);
-            const void *fn;
-            if (R == kFir1RShort) {
-                fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RShort>)
-                           : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RShort>);
-            } else {
-                fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RLong>)
-                           : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RLong>);
-            }
-            hipError_t e = ensure_dynamic_lds(fn, lds);
-            if (e != hipSuccess) return e;
-            FrontParams pp = p;
-            void *args[] = {&pp};
-            e = hipExtLaunchKernel(fn, grid, dim3(64 * kFirWgWaves), args, lds, stream, t0, t1, 0);
-            if (e != hipSuccess) return e;
-            return hipGetLastError();
+        // whole 4096-output blocks, so every bit word of the capture is written
+        const int R = fir1_R(p);
+        range((p.n_out + kFirTile - 1) / kFirTile * (kFirTile / (64 * R) / kFirWgWaves), grid, pp);
+        if (grid == 0) return hipSuccess;
+        const void *fn;
+        if (R == kFir1RShort) {
+            fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RShort>)
+                       : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RShort>);
+        } else {
+            fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RLong>)
+                       : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RLong>);
         }
+        hipError_t e = ensure_dynamic_lds(fn, lds);
+        if (e != hipSuccess) return e;
+        e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kFirWgWaves), args, lds, stream, t0, t1, 0);
+        return e != hipSuccess ? e : hipGetLastError();
     }
     if (use_fir2(p)) {
         const size_t lds = (size_t)kFir2Waves * Fir2Dec4::wave_bytes;
-        const uint64_t tiles = (p.n_out + (uint64_t)kFir2Waves * Fir2Dec4::F - 1) / ((uint64_t)kFir2Waves * Fir2Dec4::F);
-        const dim3 grid((uint32_t)tiles, num_captures), block(64 * kFir2Waves);
-        if (exact) {
-            hipExtLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, true>), grid, block, lds, stream, t0, t1, 0, p);
-        } else {
-            hipExtLaunchKernelGGL((fir2_bits_kernel<Fir2Dec4, false>), grid, block, lds, stream, t0, t1, 0, p);
-        }
-        return hipGetLastError();
+        range((p.n_out + (uint64_t)kFir2Waves * Fir2Dec4::F - 1) / ((uint64_t)kFir2Waves * Fir2Dec4::F), grid, pp);
+        if (grid == 0) return hipSuccess;
+        const void *fn = exact ? reinterpret_cast<const void *>(&fir2_bits_kernel<Fir2Dec4, true>)
+                               : reinterpret_cast<const void *>(&fir2_bits_kernel<Fir2Dec4, false>);
+        const hipError_t e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kFir2Waves), args, lds,
+                                                stream, t0, t1, 0);
+        return e != hipSuccess ? e : hipGetLastError();
     }
+    if (tile_begin != 0 || tile_count != ~0ull) return hipErrorInvalidValue;     // the generic kernel runs whole captures
     // several kernels: bracket them
     if (t0 && hipEventRecord(t0, stream) != hipSuccess) return hipGetLastError();
     const hipError_t e = launch_front_generic(p, num_captures, stream);

@@ -63,6 +63,7 @@ struct FrontParams {
                                 // (its first bit vs. the tile before NOT included)
                                 // | first bit << 30 | last bit << 31; [captures][tiles_per_cap]
     uint32_t tiles_per_cap;
+    uint32_t tile_base;         // first wave tile of this launch (set by launch_front: chunked runs)
     uint32_t sparse;            // tuned 1-stage kernels: quiet tiles store nothing (their words / infos are zero
                                 // already: launch_clear_tiles zeroed what the run before wrote)
 };
@@ -88,14 +89,18 @@ struct StreamCtl {
     uint32_t waves_per_cu;      // persistent single-wave workgroups per CU (0 = default)
     uint32_t groups_per_cap;    // filled in by the launcher: tiles_per_cap / kStreamGroup
     uint32_t num_heads;         // filled in by the launcher
+    uint32_t static_stride;     // experiment: groups dealt statically (workgroup + k * grid) instead of by ticket
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a kernel needs
 // more than it was last granted (the call costs microseconds per launch).
 hipError_t ensure_dynamic_lds(const void *func, size_t bytes);
 
+// tile_begin / tile_count: a range of the capture's wave tiles (front_tile_bits() outputs each; tuned
+// kernels only) -- the chunks of a pipelined run
 hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact, hipStream_t stream,
-                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+                        hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, uint64_t tile_begin = 0,
+                        uint64_t tile_count = ~0ull);
 // Streaming form (1 stage / decimation 1 / <= 256 taps only: front_streams()).  ctl.heads (and
 // ctl.done) must be zero when the kernel starts; write_through: bit words / tile infos are stored
 // past the L2 so that a kernel started while this one runs reads them (ctl.done tells when).
@@ -130,6 +135,10 @@ struct EdgeParams {
     uint32_t *overflow;         // set to 1 when total edges > capacity
     const uint32_t *tile_info;  // per wave tile counts from the tuned front-end kernels, or null
     uint32_t tiles_per_block;   // wave tiles per 4096-bit block (4 or 16)
+    // chunked (pipelined) runs: this launch covers one chunk of a capture, positions are chunk-local
+    uint32_t *total_acc;        // += the chunk's level changes, or null
+    uint32_t has_prev;          // bits / tile_info continue in front of the chunk: the level before its first
+                                // sample is the last bit of the chunk before (0 for a capture's or shard's start)
 };
 
 hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);
@@ -265,6 +274,11 @@ struct FsmScanArgs {
     uint64_t *errs;             // flat error list
     uint64_t err_capacity;
     const FsmStateDev *first;   // incoming state (host pointer) or null = reset
+    // chunked (pipelined) runs, one launch per chunk of one capture (all null / 0 otherwise):
+    const SegState *first_dev;  // incoming state in device memory: the chunk before's final_state
+    uint64_t pos_origin;        // the chunk's first decimated sample
+    const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device)
+    const uint32_t *edge_overflow;      // the edge stage's overflow flag (device), or null
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]

@@ -50,6 +50,15 @@ struct ResultHeader {
     uint32_t publish_done;      // workgroups of the scan's publishing kernel that are through
 };
 
+// one chunk of a pipelined single-capture run
+struct Chunk {
+    uint64_t out0, nout;        // decimated samples [out0, out0 + nout) of the capture
+    uint32_t blk0, nblk;        // 4096-output blocks
+    uint64_t edge_off, edge_cap;        // its region of the edge list
+};
+constexpr uint64_t kPipeDefaultChunk = 1ull << 28;      // input samples
+constexpr uint64_t kPipeTailChunk = 1ull << 25;         // the last chunks shrink down to this: a short exposed chain
+
 // Front-end kernels of different contexts on one device take turns: they are
 // HBM bound, so running two at once only makes both slower, while everything
 // after them (edges, state machine: latency bound) overlaps the next
@@ -268,8 +277,23 @@ struct ookd_rx {
     bool sparse = false;
     uint64_t dirty_tiles = 0, dirty_words_per_cap = 0;
     uint32_t dirty_tiles_per_cap = 0;
+    // chunk pipeline (single-capture runs): front end on s_front, edges + state machine on s_chain, each
+    // on its own half of the CUs
+    bool pipe_ok = false;
+    uint64_t pipe_chunk_in = 0;     // target input samples per chunk
+    hipStream_t s_front = nullptr, s_chain = nullptr;
+    hipEvent_t ev_start = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_c0, ev_c1;       // per chunk: front-end kernel start / stop
+    std::vector<Chunk> chunks;      // of the last run (empty: not pipelined)
+    DevBuf<SegState> d_carry;       // [2] state handed from chunk to chunk
+    DevBuf<uint64_t> d_chunk_totals;    // [2][2] messages / errors so far
+    DevBuf<uint32_t> d_fin_tickets; // [kMaxChunks] the finish kernel's work counter, one per chunk
+    const void *last_iq = nullptr;  // arguments of the last run (a refused pipelined run is redone whole)
+    uint64_t last_stride = 0;
+    bool no_pipeline_once = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
     uint32_t stream_waves = 12;     // persistent front-end waves per CU
+    uint64_t front_launch_outputs = 1ull << 27;    // decimated samples per front-end grid launch (all captures together)
 
     // device (state machine)
     bool have_fsm = false;
@@ -356,6 +380,15 @@ struct ookd_rx {
         d_tile_info.release();
         d_ctl.release();
         d_quiet.release();
+        d_carry.release();
+        d_chunk_totals.release();
+        d_fin_tickets.release();
+        for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
+        for (auto &e : ev_c1) if (e) (void)hipEventDestroy(e);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (s_front) (void)hipStreamDestroy(s_front);
+        if (s_chain) (void)hipStreamDestroy(s_chain);
         d_blk_count.release();
         d_blk_offset.release();
         d_group_total.release();
@@ -493,6 +526,9 @@ struct ookd_rx {
 
     int front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                         uint32_t halo_len);
+    bool plan_chunks();
+    int run_pipelined(const void *d_iq);
+    int prepare_front(FrontParams &fp);
     int run_state_machine(const FsmStateDev *first, bool fresh);
     int fsm_scan(const FsmStateDev *first);
     int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
@@ -504,6 +540,206 @@ struct ookd_rx {
     bool submitted = false;         // a run is queued (ookd_rx_submit_device) and not yet waited for
 };
 
+// Sparse front-end output: quiet tiles store nothing, so zero what the run before wrote and
+// remember what this one may write (on the main stream, ahead of every front-end launch).
+int ookd_rx::prepare_front(FrontParams &fp) {
+    if (sparse) {
+        // quiet tiles store nothing: zero what the run before wrote (found by its non-zero tile infos),
+        // remember what this one may write
+        HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap,
+                                  front_tile_bits(fp), stream));
+        dirty_tiles = (uint64_t)run_caps * fp.tiles_per_cap;
+        dirty_tiles_per_cap = fp.tiles_per_cap;
+        dirty_words_per_cap = run_words;
+    }
+    return OOKD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// chunk pipeline
+// ---------------------------------------------------------------------------
+// A long single capture is cut into chunks at multiples of lcm(4096 outputs,
+// samples_per_buffer): chunk boundaries are buffer boundaries (the
+// drop-rest-of-buffer rule stays chunk-local) and edge-block boundaries.  The
+// front end of chunk c+1 (s_front) runs while the edges + state machine of
+// chunk c (s_chain) run; each stream owns one half of the CUs, spread evenly
+// over the XCDs -- the front end is HBM bound and as fast on half the chip
+// (tools/cu_mask_probe.py), the chain's kernels no longer wait for a wave slot
+// beside a grid that refills every one it frees.  Every chunk is a shard of
+// the capture for the state machine: positions chunk-local, the level in
+// front of it counted as 0, the incoming state = the chunk before's outgoing
+// state, in device memory.  Messages / errors are appended behind the chunks
+// before's.  A refusal of the scan anywhere sends the whole capture through
+// the unchunked path.
+bool ookd_rx::plan_chunks() {
+    chunks.clear();
+    if (!pipe_ok || no_pipeline_once || run_caps != 1 || run_n_out == 0) return false;
+    const uint64_t spb = cfg.samples_per_buffer;
+    // boundary (decimated index) o: o % 4096 == 0 and o * D % spb == 0
+    const uint64_t per_buf = spb / gcd64(spb, total_decim);
+    const uint64_t align = (uint64_t)kFirTile / gcd64(kFirTile, per_buf) * per_buf;
+    const uint64_t target = std::max<uint64_t>(align, pipe_chunk_in / total_decim / align * align);
+    if (run_n_out < 2 * target) return false;
+    std::vector<uint64_t> sizes;
+    uint64_t left = run_n_out;
+    while (left > target + target / 2) {
+        sizes.push_back(target);
+        left -= target;
+    }
+    // the tail shrinks: the chain of the last chunk is all that is not hidden behind a front end
+    const uint64_t tail_min = std::max<uint64_t>(align, kPipeTailChunk / total_decim / align * align);
+    while (left > 2 * tail_min && sizes.size() + 2 < (size_t)kMaxChunks) {
+        uint64_t half = left / 2 / align * align;
+        if (half < tail_min) break;
+        sizes.push_back(half);
+        left -= half;
+    }
+    sizes.push_back(left);
+    if (sizes.size() < 2 || sizes.size() > (size_t)kMaxChunks) return false;
+    uint64_t at = 0, eoff = 0;
+    for (uint64_t sz : sizes) {
+        Chunk c{};
+        c.out0 = at;
+        c.nout = sz;
+        c.blk0 = (uint32_t)(at / kFirTile);
+        c.nblk = (uint32_t)((sz + kFirTile - 1) / kFirTile);
+        c.edge_off = eoff;
+        c.edge_cap = edge_capacity / run_blocks * c.nblk;       // its share of the list, by blocks
+        eoff += c.edge_cap;
+        at += sz;
+        chunks.push_back(c);
+    }
+    return true;
+}
+
+int ookd_rx::run_pipelined(const void *d_iq) {
+    const size_t nc = chunks.size();
+    while (ev_c0.size() < nc) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreate(&a));
+        ev_c0.push_back(a);
+        HIPCHK(hipEventCreate(&b));
+        ev_c1.push_back(b);
+    }
+    if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    hdr_dirty = true;
+    if (count_quiet) HIPCHK(hipMemsetAsync(d_quiet.p, 0, sizeof(uint32_t) * kQuietCounters, stream));
+    HIPCHK(hipMemsetAsync(d_fin_tickets.p, 0, sizeof(uint32_t) * nc, stream));
+    FrontParams fp = front_params(d_iq, run_n_valid);
+    {
+        const int rc = prepare_front(fp);
+        if (rc != OOKD_OK) return rc;
+    }
+    HIPCHK(hipEventRecord(ev_start, stream));
+    HIPCHK(hipStreamWaitEvent(s_front, ev_start, 0));
+    HIPCHK(hipStreamWaitEvent(s_chain, ev_start, 0));
+
+    const uint32_t tile_bits = front_tile_bits(fp);
+    const uint32_t tiles_per_block = (uint32_t)kFirTile / tile_bits;
+    scan_used = false;
+    scan_pending = true;
+    stats.fsm_path = 0;
+    stats.fsm_fallback_reason = 0;
+    pending_first_valid = false;
+    // every front-end launch first: the device starts on the capture at once and is not held up by
+    // the host still queueing the (ten times as many) chain kernels behind
+    for (size_t c = 0; c < nc; ++c) {
+        const Chunk &ch = chunks[c];
+        HIPCHK(launch_front(fp, 1, exact, s_front, ev_c0[c], ev_c1[c], (uint64_t)ch.blk0 * tiles_per_block,
+                            (uint64_t)ch.nblk * tiles_per_block));
+    }
+    for (size_t c = 0; c < nc; ++c) {
+        const Chunk &ch = chunks[c];
+        const bool last = c + 1 == nc;
+        HIPCHK(hipStreamWaitEvent(s_chain, ev_c1[c], 0));
+        // ---- its edges: chunk-local positions ----------------------------------------------------------
+        EdgeParams e{};
+        e.bits = d_bits.p + (size_t)ch.blk0 * kBlockWords;
+        e.words_per_cap = (uint64_t)ch.nblk * kBlockWords;
+        e.n_out = ch.nout;
+        e.num_captures = 1;
+        e.blocks_per_cap = ch.nblk;
+        e.blk_count = d_blk_count.p + ch.blk0;
+        e.blk_offset = d_blk_offset.p + ch.blk0 + c;            // nblk + 1 entries per chunk
+        e.group_total = d_group_total.p;
+        e.edges = d_edges.p + ch.edge_off;
+        e.edge_capacity = ch.edge_cap;
+        e.overflow = &d_hdr.p->edge_overflow;
+        e.tile_info = d_tile_info.p + (size_t)ch.blk0 * tiles_per_block;
+        e.tiles_per_block = tiles_per_block;
+        e.total_acc = &d_hdr.p->total_edges;
+        e.has_prev = c ? 1u : 0u;
+        HIPCHK(launch_edges(e, s_chain));
+        // ---- its state machine, from the chunk before's outgoing state --------------------------------------
+        FsmScanArgs a{};
+        a.f = fsm_params();
+        a.f.bits = e.bits;
+        a.f.words_per_cap = e.words_per_cap;
+        a.f.edges = e.edges;
+        a.f.blk_offset = e.blk_offset;
+        a.f.blocks_per_cap = ch.nblk;
+        a.f.num_captures = 1;
+        a.f.n_out = ch.nout;
+        a.f.totals = last ? d_hdr.p->totals : d_chunk_totals.p + 2 * (c & 1);
+        a.D = scan_D;
+        a.S = scan_S;
+        a.SNB = scan_S * (scan_max_bits + 2);
+        a.leaf_block = scan_leaf_block;
+        a.grid_blocks = 1024;
+        a.block_tab = d_block_tab.p;
+        a.chunk_tab = d_chunk_tab.p;
+        a.lt_off = d_lt_off.p;
+        a.lt_n0 = d_lt_n0.p;
+        a.lt_pk = d_lt_pk.p;
+        a.ltab = d_ltab.p;
+        a.reach = d_reach.p;
+        a.nreach = (uint32_t)d_reach.n;
+        a.nreach_base = scan_reach_base;
+        if (last) {
+            a.publish = publish_params();
+            a.publish.total_edges = nullptr;        // accumulated in the header by the edge stages
+        } else {
+            // messages go to the host as they are resolved; the header only with the last chunk
+            PublishParams pp{};
+            pp.d_msgs = reinterpret_cast<const uint4 *>(d_msgs.p);
+            pp.h_msgs = reinterpret_cast<uint4 *>(h_msgs_dev);
+            pp.first_msgs = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
+            a.publish = pp;
+        }
+        a.leaf_res = d_leaf_res.p;
+        a.cap_group_off = d_cap_group_off.p;
+        a.group_tab = d_group_tab.p;
+        a.group_in = d_group_in.p;
+        a.cap_end = d_cap_end.p;
+        a.cap_first = d_cap_end.p + (max_captures + 8);
+        a.cap_block_off = d_cap_block_off.p;
+        a.total_blocks_cap = scan_blocks_cap;
+        a.events = d_events.p;
+        a.app_vals = d_app_vals.p;
+        a.app_capacity = d_app_vals.n - 64;
+        a.errs = d_scan_errs.p;
+        a.err_capacity = d_scan_errs.n;
+        a.first = nullptr;
+        a.first_dev = c ? d_carry.p + ((c - 1) & 1) : nullptr;
+        a.pos_origin = ch.out0;
+        a.totals_in = c ? d_chunk_totals.p + 2 * ((c - 1) & 1) : nullptr;
+        a.edge_overflow = &d_hdr.p->edge_overflow;
+        a.final_state = d_carry.p + (c & 1);
+        a.fallback = &d_hdr.p->scan_fallback;
+        a.fin_off = d_fin_off.p;
+        a.fsum = d_fsum.p;
+        a.fin_ticket = d_fin_tickets.p + c;
+        if (++scan_stamp == 0) scan_stamp = 1;
+        a.run_stamp = scan_stamp;
+        a.fin_blocks_cap = scan_fin_cap;
+        HIPCHK(launch_fsm_scan(a, s_chain, last ? ev[2] : nullptr));
+    }
+    scan_published = true;
+    HIPCHK(hipEventRecord(ev_end, s_chain));
+    HIPCHK(hipStreamWaitEvent(stream, ev_end, 0));
+    return OOKD_OK;
+}
+
 int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                              uint32_t halo_len) {
     if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
@@ -512,13 +748,9 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
-    if (sparse) {
-        // quiet tiles store nothing: zero what the run before wrote, remember what this one may write
-        HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap,
-                                  front_tile_bits(fp), stream));
-        dirty_tiles = (uint64_t)run_caps * fp.tiles_per_cap;
-        dirty_tiles_per_cap = fp.tiles_per_cap;
-        dirty_words_per_cap = run_words;
+    {
+        const int rc = prepare_front(fp);
+        if (rc != OOKD_OK) return rc;
     }
     if (!front_grid && front_streams(fp)) {
         // persistent streaming form: capped residency, other contexts' kernels run beside it
@@ -530,17 +762,40 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
         ctl.num_chunks = 0;
         ctl.num_caps = run_caps;
         ctl.waves_per_cu = stream_waves;
+        ctl.static_stride = getenv("OOKD_STREAM_STRIDE") ? 1u : 0u;
         HIPCHK(launch_front_stream(fp, ctl, exact, false, stream, ev[0], ev[1]));
-    } else if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
-        // wait + launch + publish under the lock: the event must be on its way before another
-        // context may wait for it
-        std::lock_guard<std::mutex> lock(g_gate.m);
-        hipEvent_t prev = g_gate.last[dev];
-        if (prev && prev != ev[1]) HIPCHK(hipStreamWaitEvent(stream, prev, 0));
-        HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));
-        g_gate.last[dev] = ev[1];
     } else {
-        HIPCHK(launch_front(fp, run_caps, exact, stream, ev[0], ev[1]));    // ev[0], ev[1]: the kernel's own time stamps
+        // The tuned kernels go out as several grid launches of front_launch_tiles wave tiles: while a
+        // grid has workgroups left to dispatch, kernels of OTHER queues (the edges / state machine
+        // chain of the capture before, on another context's stream) are hardly dispatched at all --
+        // they get their turn when a front-end launch has drained (profiles/r02_pipeline_trace.txt),
+        // and once dispatched they run beside the next launch.  ev[0] / ev[1] = start of the first,
+        // end of the last launch.
+        const uint32_t tile_bits = front_tile_bits(fp);
+        const uint64_t tiles = tile_bits ? (uint64_t)fp.tiles_per_cap : 0;
+        const uint64_t per = tile_bits ? std::max<uint64_t>(1, front_launch_outputs / tile_bits / std::max(1u, run_caps)) : 0;
+        auto launch_all = [&]() -> hipError_t {
+            if (!tile_bits || tiles <= per + per / 2) return launch_front(fp, run_caps, exact, stream, ev[0], ev[1]);
+            for (uint64_t t = 0; t < tiles; t += per) {
+                const bool first = t == 0, last = t + per >= tiles;
+                const hipError_t e = launch_front(fp, run_caps, exact, stream, first ? ev[0] : nullptr,
+                                                  last ? ev[1] : nullptr, t, per);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        };
+        if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
+            // front ends of different contexts take turns (HBM bound: two at once only slow each other);
+            // wait + launch + publish under the lock: the event must be on its way before another
+            // context may wait for it
+            std::lock_guard<std::mutex> lock(g_gate.m);
+            hipEvent_t prev = g_gate.last[dev];
+            if (prev && prev != ev[1]) HIPCHK(hipStreamWaitEvent(stream, prev, 0));
+            HIPCHK(launch_all());
+            g_gate.last[dev] = ev[1];
+        } else {
+            HIPCHK(launch_all());
+        }
     }
     if (run_n_out > 0) HIPCHK(launch_edges(edge_params(), stream));
     return OOKD_OK;
@@ -771,6 +1026,24 @@ int ookd_rx::collect_results() {
         if (h_hdr->scan_fallback == 0) {
             scan_used = true;
             stats.fsm_path = 1;
+        } else if (!chunks.empty()) {
+            // the scan refused a chunk of a pipelined run: the whole capture again, unchunked (the
+            // last chunk's publishing kernel left the device header zeroed)
+            stats.fsm_fallback_reason = h_hdr->scan_fallback;
+            if (getenv("OOKD_DEBUG")) {
+                fprintf(stderr, "[ookd] pipelined run refused (reason %u), running the capture whole\n", h_hdr->scan_fallback);
+            }
+            chunks.clear();
+            no_pipeline_once = true;
+            const uint32_t reason = stats.fsm_fallback_reason;
+            int rc = front_and_edges(last_iq, last_stride, nullptr, 0);
+            if (rc == OOKD_OK) rc = run_state_machine(nullptr, true);
+            if (rc == OOKD_OK) rc = enqueue_publish();
+            no_pipeline_once = false;
+            if (rc != OOKD_OK) return rc;
+            rc = collect_results();
+            if (stats.fsm_fallback_reason == 0) stats.fsm_fallback_reason = reason;
+            return rc;
         } else {
             // the scan refused this capture: run the round path and fetch again
             stats.fsm_fallback_reason = h_hdr->scan_fallback;
@@ -809,8 +1082,19 @@ int ookd_rx::collect_results() {
     stats.decimated_samples = run_n_out;
     stats.num_segments = run_caps * run_segs_per_cap;
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats.fir_kernel_ms = ms;
-    if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
+    if (!chunks.empty()) {
+        // pipelined: the front-end kernels of all chunks; first kernel start -> last kernel end
+        stats.pipeline_chunks = (uint32_t)chunks.size();
+        float sum = 0.0f;
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            if (hipEventElapsedTime(&ms, ev_c0[c], ev_c1[c]) == hipSuccess) sum += ms;
+        }
+        stats.fir_kernel_ms = sum;
+        if (hipEventElapsedTime(&ms, ev_c0[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
+    } else {
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats.fir_kernel_ms = ms;
+        if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
+    }
     if (h_hdr->edge_overflow) {
         set_error("edge list overflow: %u level changes found, capacity %llu "
                   "(raise ookd_rx_config.edge_capacity)",
@@ -1017,7 +1301,8 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     // slower than the hardware-dispatched grid; OOKD_FRONT_STREAM=1 selects it
     rx->front_grid = (cfg->flags & OOKD_RX_FRONT_GRID) != 0 || !getenv("OOKD_FRONT_STREAM");
     if (const char *w = getenv("OOKD_STREAM_WAVES")) rx->stream_waves = (uint32_t)std::max(1, atoi(w));
-    rc |= rx->d_blk_offset.alloc(caps * blocks + 1);
+    if (const char *w = getenv("OOKD_FRONT_LAUNCH_LOG2")) rx->front_launch_outputs = 1ull << std::min(40, std::max(16, atoi(w)));
+    rc |= rx->d_blk_offset.alloc(caps * blocks + 1 + kMaxChunks);     // (a pipelined run keeps one total per chunk)
     rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
     rc |= rx->d_hdr.alloc(1);
@@ -1145,6 +1430,63 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         set_error("pinned result buffers are not mapped into the device");
         return nullptr;
     }
+    // ---- chunk pipeline: two internal streams, each on its own half of the CUs -----------------------
+    {
+        FrontParams probe = rx->front_params(nullptr, 0);
+        probe.n_out = rx->max_n_out;
+        const bool tuned = front_tile_bits(probe) != 0;
+        // off unless asked for (pipeline_chunk_samples, or OOKD_PIPELINE=1 for the default chunk): with the
+        // hardware-dispatched front end the chain's kernels are hardly dispatched while a front-end grid
+        // has workgroups pending, and the chunked run is slower than the whole one
+        uint64_t want = cfg->pipeline_chunk_samples;
+        if (!want && getenv("OOKD_PIPELINE")) want = kPipeDefaultChunk;
+        rx->pipe_chunk_in = want ? want : kPipeDefaultChunk;
+        rx->pipe_ok = want != 0 && rx->have_fsm && rx->scan_ok && tuned && !(cfg->flags & OOKD_RX_NO_PIPELINE) &&
+                      cfg->pipeline_chunk_samples != ~0ull && !getenv("OOKD_NO_PIPELINE") &&
+                      rx->max_n_out >= 2 * (rx->pipe_chunk_in / rx->total_decim);
+    }
+    if (rx->pipe_ok) {
+        // every other CU of every XCD for the front end, the rest for the chain (an UNEVEN mask
+        // slows the front end: the dispatcher deals workgroups evenly over the XCDs).
+        // OOKD_PIPE_MASKS=front,chain (hex, per 32 CUs; 0 = no mask) overrides.
+        uint32_t mf = 0x55555555u, mc = 0xAAAAAAAAu;
+        if (const char *m = getenv("OOKD_PIPE_MASKS")) {
+            char *end = nullptr;
+            mf = (uint32_t)strtoul(m, &end, 16);
+            mc = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 16) : 0u;
+        }
+        auto make = [&](hipStream_t &s, uint32_t pattern) {
+            if (pattern == 0) return hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            uint32_t mask[8];
+            for (auto &w : mask) w = pattern;
+            hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
+            if (e != hipSuccess) {          // (no CU masking on this system: plain streams still pipeline)
+                (void)hipGetLastError();
+                e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+            }
+            return e;
+        };
+        bool made = make(rx->s_front, mf) == hipSuccess;
+        if (const char *k = getenv("OOKD_PIPE_DUMMY")) {       // experiment: shift the queue -> pipe assignment
+            for (int i = 0; i < atoi(k); ++i) {
+                hipStream_t d = nullptr;
+                (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking);
+                // a queue only exists once something was submitted to it
+                (void)hipMemsetAsync(rx->d_hdr.p, 0, 4, d);
+                (void)hipStreamSynchronize(d);
+            }
+        }
+        if (!made || make(rx->s_chain, mc) != hipSuccess ||
+            hipEventCreateWithFlags(&rx->ev_start, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&rx->ev_end, hipEventDisableTiming) != hipSuccess) {
+            set_error("creating the pipeline streams failed");
+            return nullptr;
+        }
+        if (rx->d_carry.alloc(2) != OOKD_OK || rx->d_chunk_totals.alloc(4) != OOKD_OK ||
+            rx->d_fin_tickets.alloc(kMaxChunks) != OOKD_OK) {
+            return nullptr;
+        }
+    }
     if (rx->dev >= 0 && rx->dev < kMaxGateDevices) {
         g_live_contexts[rx->dev].fetch_add(1);
         rx->counted = true;
@@ -1181,6 +1523,14 @@ int ookd_rx_submit_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
     rx->geometry(samples_per_capture, true, rx->run_n_in, rx->run_n_out, rx->run_words,
                  rx->run_blocks, rx->run_segs_per_cap);
     rx->stats = ookd_rx_stats{};
+    rx->last_iq = d_iq;
+    rx->last_stride = capture_stride_samples;
+    if (rx->plan_chunks()) {
+        const int rcp = rx->run_pipelined(d_iq);
+        if (rcp != OOKD_OK) return rcp;
+        rx->submitted = true;
+        return OOKD_OK;
+    }
     int rc = rx->front_and_edges(d_iq, capture_stride_samples, nullptr, 0);
     if (rc != OOKD_OK) return rc;
     rc = rx->run_state_machine(nullptr, true);
@@ -1310,6 +1660,7 @@ int ookd_rx_shard_begin(ookd_rx *rx, const void *d_iq, uint64_t num_samples, con
     rx->run_n_valid = num_samples;
     rx->geometry(num_samples, last_shard != 0, rx->run_n_in, rx->run_n_out, rx->run_words,
                  rx->run_blocks, rx->run_segs_per_cap);
+    rx->chunks.clear();
     rx->stats = ookd_rx_stats{};
     int rc = rx->front_and_edges(d_iq, num_samples, hl ? rx->d_halo.p : nullptr, hl);
     if (rc != OOKD_OK) return rc;
@@ -1393,6 +1744,23 @@ int ookd_rx_get_edges(const ookd_rx *rx, uint32_t capture, uint64_t *edges, uint
     HIPCHK(hipSetDevice(rx->dev));
     if (rx->run_n_out == 0) {
         if (num_edges) *num_edges = 0;
+        return OOKD_OK;
+    }
+    if (!rx->chunks.empty()) {
+        // pipelined run: one list per chunk, positions chunk-local
+        std::vector<uint64_t> all;
+        for (size_t c = 0; c < rx->chunks.size(); ++c) {
+            const Chunk &ch = rx->chunks[c];
+            uint32_t ne = 0;
+            HIPCHK(hipMemcpy(&ne, rx->d_blk_offset.p + ch.blk0 + c + ch.nblk, 4, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> loc(std::min<uint64_t>(ne, ch.edge_cap));
+            if (!loc.empty()) {
+                HIPCHK(hipMemcpy(loc.data(), rx->d_edges.p + ch.edge_off, loc.size() * 8, hipMemcpyDeviceToHost));
+            }
+            for (uint64_t e : loc) all.push_back(e + ch.out0);
+        }
+        if (num_edges) *num_edges = all.size();
+        if (edges && !all.empty()) memcpy(edges, all.data(), std::min<uint64_t>(all.size(), capacity) * 8);
         return OOKD_OK;
     }
     uint32_t off[2];

@@ -62,13 +62,20 @@ def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, chec
     n = iq.size // 2
     want = oracle.rx(iq, of, thr, od, spb, want_bits=True, want_fir=check_fir)
     got = None
-    # state machine forms: scan with span tables, scan simulating every span, rounds
-    for fsm_rounds, scan_sims in ((False, False), (False, True), (True, False)):
+    # state machine forms: scan with span tables, scan simulating every span, rounds; then the scan
+    # again with the capture pipelined in small chunks (front end of chunk c+1 beside the state
+    # machine of chunk c, state carried on the device) and with the round-1 grid front end
+    for fsm_rounds, scan_sims, chunk, grid in ((False, False, 0, False), (False, True, 0, False), (True, False, 0, False),
+                                               (False, False, 4 * spb, False), (False, False, 0, True)):
         rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
                          exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
-                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims)
+                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims,
+                         pipeline_chunk_samples=chunk, front_grid=grid)
         got = rx.rx(iq)
         assert got.stats["decimated_samples"] == want.decimated
+        if chunk and expect_scan and spb % 4096 == 0 and n >= 16 * spb and got.stats["fsm_fallback_reason"] == 0:
+            assert got.stats["pipeline_chunks"] >= 2, "the capture was not pipelined"
+        assert got.stats["num_edges"] == len(edges_of(want.bits))
         if want.decimated:
             assert got.stats["fsm_path"] == (2 if fsm_rounds else (1 if expect_scan else got.stats["fsm_path"]))
         bits = rx.bits()
@@ -836,6 +843,38 @@ def test_context_is_reusable_across_sizes(ok, oracle, vectors):
         assert list(got.msg_samples) == list(want.msg_samples), n
         assert (got.payloads == want.payloads).all()
         assert list(rx.edges()) == list(edges_of(want.bits)), n
+    rx.close()
+
+
+@pytest.mark.parametrize("chunk,stream_form", [(0, False), (32768, False), (0, True)])
+def test_sparse_bit_words_do_not_leak_between_runs(ok, oracle, vectors, chunk, stream_form, monkeypatch):
+    """The tuned 1-stage front end stores nothing for quiet tiles: what a run wrote is zeroed by
+    the next one (by the front end itself when the layout repeats, by a pass over the old tile
+    infos when it changes).  Different captures of equal and of different lengths through one
+    context, whole and pipelined in chunks, hardware-dispatched and streaming front end: bits,
+    edges and messages of every run must be the oracle's."""
+    if stream_form:
+        monkeypatch.setenv("OOKD_FRONT_STREAM", "1")
+    g, a = _g1(vectors, noise_seed=41)
+    rng = np.random.default_rng(42)
+    shift = 2 * 77000                       # the same waveform moved: pulses where A has silence
+    b = np.concatenate([rng.integers(-40, 41, size=shift).astype(np.int16), a[:-shift]])
+    c = rng.integers(-40, 41, size=a.size).astype(np.int16)         # silence: nothing may survive
+    f = _flt(ok, "fs32_fs4")
+    of = _ofir(oracle, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    rx = ok.Receiver(f, d, max_samples=a.size // 2, pipeline_chunk_samples=chunk)
+    for name, iq in (("a", a), ("b", b), ("c", c), ("a", a), ("b half", b[:b.size // 2]), ("a", a), ("c third", c[:2 * 400000]),
+                     ("b", b)):
+        got = rx.rx(iq)
+        want = oracle.rx(iq, of, 0.1, od, 8192, want_bits=True)
+        bits = rx.bits()
+        diff = np.nonzero(bits != want.bits)[0]
+        assert diff.size == 0, "%s: first differing bit at %s" % (name, diff[:5])
+        assert list(rx.edges()) == list(edges_of(want.bits)), name
+        assert list(got.msg_samples) == list(want.msg_samples), name
+        assert (got.payloads == want.payloads).all(), name
     rx.close()
 
 
