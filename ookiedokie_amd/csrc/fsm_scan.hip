@@ -2227,11 +2227,37 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     if (e != hipSuccess) return e;
     const uint32_t caps = a.f.num_captures;
     const uint32_t cap_grid = caps < 256 ? caps : 256;
+    // leaf / emit are persistent grids: exactly as many workgroups as the chip holds at once (a
+    // second, thinner round of the 1024 there used to be cost a third of their time)
+    static thread_local int sim_dev = -1;
+    static thread_local uint32_t sim_grid = 0;
+    static thread_local size_t sim_lds = 0;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev != sim_dev || lds != sim_lds) {
+            int per_cu_leaf = 0, per_cu_emit = 0, cus = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_leaf, scan_leaf_kernel, kSimThreads, lds) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_emit, scan_emit_kernel, kSimThreads, lds) == hipSuccess &&
+                hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+                cus = prop.multiProcessorCount;
+                const int per_cu = per_cu_leaf < per_cu_emit ? per_cu_leaf : per_cu_emit;
+                sim_grid = per_cu > 0 && cus > 0 ? (uint32_t)(per_cu * cus) : a.grid_blocks;
+            } else {
+                (void)hipGetLastError();
+                sim_grid = a.grid_blocks;
+            }
+            sim_dev = dev;
+            sim_lds = lds;
+        }
+    }
+    const uint32_t sim_blocks = getenv("OOKD_SCAN_GRID") ? (uint32_t)atoi(getenv("OOKD_SCAN_GRID")) : sim_grid;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
-    hipLaunchKernelGGL(scan_leaf_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
+    hipLaunchKernelGGL(scan_leaf_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
     hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
-    hipLaunchKernelGGL(scan_emit_kernel, dim3(a.grid_blocks), dim3(kSimThreads), lds, stream, sp);
+    hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
     // t_end takes the last kernel's own end time stamp (no marker packet behind the chain)

@@ -293,7 +293,7 @@ struct ookd_rx {
     bool no_pipeline_once = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
     uint32_t stream_waves = 12;     // persistent front-end waves per CU
-    uint64_t front_launch_outputs = 1ull << 27;    // decimated samples per front-end grid launch (all captures together)
+    uint64_t front_launch_outputs = 1ull << 29;    // decimated samples per front-end grid launch (all captures together)
 
     // device (state machine)
     bool have_fsm = false;
