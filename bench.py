@@ -1,29 +1,46 @@
 #!/usr/bin/env python3
 """bench.py -- IQ Msamples/s demodulated (SC16Q11 -> bits/messages) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload capture|batch|sharded]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted
-on): one 1 GiB synthetic SC16Q11 capture (268 435 456 samples, recipe of
-SURVEY.md 8(d), seed base+2+rank) resident in HBM, fs32_fs4.json FIR,
-p3l-nexa2012 decoder, threshold 0.1, 8192 samples per buffer, 3 Msps.
-A step = one pass of the whole hot path over that capture: unpack + FIR +
-threshold + bit packing, edge extraction, symbol state machine, decoded
-messages back in host memory.  With N > 1 every rank demodulates its own
-capture (independent captures shard with no data-path collective: weak
-scaling); the value is the whole-job aggregate.
+Workload `capture` (default; BASELINE.json north_star: "a 16 GiB synthetic
+SC16Q11 stream through the fs32_fs4 FIR + p3l-nexa2012 decoder"): synthetic
+captures of 4 294 967 296 samples (recipe of SURVEY.md 8(d), one seed per
+capture) resident in HBM, fs32_fs4.json FIR, p3l-nexa2012 decoder, threshold
+0.1, 8192 samples per buffer, 3 Msps.  A step = one pass of the whole hot path
+over one capture through the C ABI (ookd_rx_submit_device + ookd_rx_wait):
+unpack + FIR + threshold + bit packing, edge extraction, symbol state machine,
+decoded messages back in host memory.  By default three rx contexts are in
+flight, each on its OWN capture: step k+1 is submitted before step k is waited
+for, so its HBM-bound front end runs beside the latency-bound state machine of
+the steps before.  With N > 1 every rank demodulates its own captures
+(independent captures shard with no data-path collective: weak scaling); the
+value is the whole-job aggregate.
+
+Other workloads (BASELINE.json configs[3] / [4], per rank): `batch` = 128
+independent captures of 2^24 samples in one batched call; `sharded` = one
+capture cut into WORLD_SIZE shards, halo + carried state machine state
+exchanged over torch.distributed (nccl = RCCL on the GPU box).
 
 One JSON line is printed by rank 0, with `roofline` for the dominant kernel
 (fused FIR front end, timed with HIP events on its own stream inside the
-library) and, at N = 1, `cpu_baseline`: the CPU oracle (plain-C restatement
-of the reference path, 1 thread like the reference) timed on this host on a
-bounded slice of the same capture -- also used as a final parity check.
+library), `single_context` (the same steps strictly one after the other),
+`worst_case` (every window filtered: no quiet shortcut) and, at N = 1,
+`cpu_baseline`: the CPU oracle (plain-C restatement of the reference path, 1
+thread like the reference) timed on this host on a bounded slice of the same
+capture -- also used as a parity check -- and the same code on all host cores.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (fresh
+processes, before anything touches a GPU) and fails if the box has fewer
+devices.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,7 +48,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_SAMPLES = 1 << 28                 # 1 GiB of SC16Q11
+N_SAMPLES = 1 << 32                 # 16 GiB of SC16Q11: the north_star capture
+BATCH_CAPTURES, BATCH_SAMPLES = 128, 1 << 24        # configs[3], one GPU's share
 SEED_BASE = 0x00C0FFEE
 RATE = 3000000
 SPB = 8192
@@ -40,29 +58,61 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3            # vector fp32 peak
 BYTES_PER_SAMPLE = 4.125            # 4 B read + 1/8 B written per decimated sample (D = 1)
 FIR_FLOP_PER_SAMPLE = 128.0         # 32 real taps x (re, im) x (mul + add)
-CPU_SLICE = 1 << 28             # the whole bench capture: ~5 s of one host core, and a full-size parity check
+CPU_SLICE = 1 << 28                 # 1 GiB slice for the CPU baseline: ~5 s of one host core
 
 
 def golden(kind, name):
     return os.path.join(ROOT, "tests", "golden", kind, name + ".json")
 
 
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: N fresh worker processes, one per GPU.  Nothing in this
+    process has touched a GPU (device_count() does not initialise one)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report fewer ranks than asked for"
+                         % (args.gpus, ndev))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--samples", type=int, default=N_SAMPLES, help=argparse.SUPPRESS)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("capture", "batch", "sharded"), default="capture")
+    ap.add_argument("--samples", type=int, default=0, help="samples per capture / per shard (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the single_context / worst_case runs")
     ap.add_argument("--exact", action="store_true", help="unfused reference-order FIR everywhere")
     ap.add_argument("--filter", default="fs32_fs4", help=argparse.SUPPRESS)   # experiments only
     ap.add_argument("--contexts", type=int, default=3,
-                    help="rx contexts (= HIP streams) with a capture in flight: with 2 or 3 the memory-bound front "
-                         "end of one step runs while the state machine of the steps before finishes (3 measured "
-                         "best: +8 %% over 2, 4 is worse again); 1 = strictly one step after the other")
+                    help="rx contexts (= HIP streams) with a capture in flight, each on its own capture: the memory-bound "
+                         "front end of one step runs beside the state machine of the steps before; 1 = strictly one "
+                         "step after the other")
     ap.add_argument("--no-quiet-skip", action="store_true",
                     help="filter every window, even those provably below the threshold (worst case)")
+    ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL; gloo when ranks share a GPU)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)               # does not return
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import numpy as np
     import torch
@@ -70,225 +120,333 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     ndev = torch.cuda.device_count()
-    shared_gpu = local_rank >= ndev         # rehearsal only: more ranks than GPUs on this box
+    shared_gpu = ndev < world               # rehearsal only: more ranks than GPUs on this box
     local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
-        if shared_gpu or ndev < world:
-            dist.init_process_group("gloo")         # RCCL refuses two ranks on one device
-        else:
+        backend = args.backend or ("gloo" if shared_gpu else "nccl")     # RCCL refuses two ranks on one device
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     ok.lib()
-    n = args.samples
     flt = ok.Filter.load(golden("filters", args.filter)) if args.filter != "none" else None
-    dev = ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // (flt.total_decimation if flt else 1))
-
-    # ---- synthetic capture generated directly in HBM ----------------------------------
-    syn = ok.Synth(dev, n, seed=SEED_BASE + 2 + rank, sample_rate=RATE)
-    capture = torch.empty(2 * n + 64, dtype=torch.int16, device="cuda")
-    syn.fill_device(capture.data_ptr(), hip_device=local_rank)
-    torch.cuda.synchronize()
-
-    nctx = max(1, args.contexts)
-    rxs = [ok.Receiver(flt, dev, max_samples=n, threshold=THRESHOLD, samples_per_buffer=SPB,
-                       hip_device=local_rank, exact_fir=args.exact, quiet_skip=not args.no_quiet_skip)
-           for _ in range(nctx)]
-    rx = rxs[0]
+    decim = flt.total_decimation if flt else 1
+    dev = ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // decim)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    res = None
-    for i in range(max(args.warmup, nctx)):
-        res = rxs[i % nctx].rx_device(capture.data_ptr(), n)
-    fir_ms, dev_ms = [], []
-    # One step = one capture through the C ABI: submit queues the whole hot path on the
-    # context's stream, wait returns with the decoded messages in host memory.  With several
-    # contexts step k+1 is submitted before step k is waited for, so its front end (HBM
-    # bound) runs beside the state machine of step k (latency bound); every step is still
-    # one complete pass over the capture, and all K complete inside the timed bracket.
-    # The ctypes objects are bound once so the loop measures the library, not Python.
     import ctypes as C
     L = ok.lib()
     submit, wait, get_stats = L.ookd_rx_submit_device, L.ookd_rx_wait, L.ookd_rx_get_stats
-    handles, ptr = [r._h for r in rxs], C.c_void_p(capture.data_ptr())
-    st = ok.RxStats()
-    st_ref = C.byref(st)
 
-    def finish(h):
-        if wait(h) != 0:
-            raise SystemExit("ookd_rx_wait failed: " + ok.last_error())
-        get_stats(h, st_ref)
-        fir_ms.append(st.fir_kernel_ms)
-        dev_ms.append(st.total_device_ms)
+    def receiver(n, caps=1, **kw):
+        return ok.Receiver(flt, dev, max_samples=n, max_captures=caps, threshold=THRESHOLD, samples_per_buffer=SPB,
+                           hip_device=local_rank, exact_fir=args.exact, **kw)
 
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        h = handles[k % nctx]
-        if k >= nctx:
-            finish(h)                   # step k - nctx ran on this context
-        if submit(h, ptr, 1, n, n) != 0:
-            raise SystemExit("ookd_rx_submit_device failed: " + ok.last_error())
-    for k in range(max(0, args.steps - nctx), args.steps):
-        finish(handles[k % nctx])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    res = rxs[(args.steps - 1) % nctx].result()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    def synth_capture(n, seed):
+        syn = ok.Synth(dev, n, seed=seed, sample_rate=RATE)
+        buf = torch.empty(2 * n + 64, dtype=torch.int16, device="cuda")
+        syn.fill_device(buf.data_ptr(), hip_device=local_rank)
+        return buf, syn
+
+    def timed_steps(handles, ptrs, ncaps, n, stride, steps):
+        """K steps over the contexts round-robin; returns seconds and the per-step kernel / device times."""
+        fir_ms, dev_ms = [], []
+        st = ok.RxStats()
+        st_ref = C.byref(st)
+        nctx = len(handles)
+
+        def finish(h):
+            if wait(h) != 0:
+                raise SystemExit("ookd_rx_wait failed: " + ok.last_error())
+            get_stats(h, st_ref)
+            fir_ms.append(st.fir_kernel_ms)
+            dev_ms.append(st.total_device_ms)
+
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            h = handles[k % nctx]
+            if k >= nctx:
+                finish(h)                   # step k - nctx ran on this context
+            if submit(h, ptrs[k % nctx], ncaps, n, stride) != 0:
+                raise SystemExit("ookd_rx_submit_device failed: " + ok.last_error())
+        for k in range(max(0, steps - nctx), steps):
+            finish(handles[k % nctx])
+        barrier()
+        return time.perf_counter() - t0, fir_ms, dev_ms
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
+    nctx = max(1, args.contexts)
     out = None
-    quiet_frac = 0.0
-    if rank == 0 and not args.no_quiet_skip:
-        # untimed diagnostic pass: how many 1024-output windows took the quiet shortcut
-        cnt = ok.Receiver(flt, dev, max_samples=n, threshold=THRESHOLD, samples_per_buffer=SPB,
-                          hip_device=local_rank, exact_fir=args.exact, count_quiet=True)
-        st = cnt.rx_device(capture.data_ptr(), n).stats
-        quiet_frac = st["quiet_waves"] / max(1, st["total_waves"])
-        cnt.close()
-    if rank == 0:
-        total_samples = float(n) * args.steps * world
-        value = total_samples / elapsed / 1e6
-        fir_avg_ms = float(np.mean(fir_ms))
-        achieved_gbs = BYTES_PER_SAMPLE * n / (fir_avg_ms * 1e-3) / 1e9
-        # flops actually executed: quiet windows skip the filter altogether
-        fir_tflops = FIR_FLOP_PER_SAMPLE * n * (1.0 - quiet_frac) / (fir_avg_ms * 1e-3) / 1e12
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                with open(prof) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "IQ Msamples/s demodulated (SC16Q11->bits)",
-            "value": round(value, 1),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "configs[1]: 1 GiB synthetic SC16Q11 capture per GPU, fs32_fs4 FIR, "
-                            "p3l-nexa2012 state machine",
-                "samples_per_capture": n, "captures_per_gpu": 1, "filter": args.filter,
-                "device": "p3l-nexa2012", "sample_rate": RATE, "threshold": THRESHOLD,
-                "samples_per_buffer": SPB, "fir_mode": "exact" if args.exact else "fma+guard-band",
-                "parallelism": "independent captures per rank, no collective",
-                "messages_per_capture": int(len(res.msg_samples)),
-                "edges_per_capture": int(res.stats["num_edges"]),
-                "fsm_rounds": int(res.stats["fsm_iterations"]),
-                "guard_recomputes": int(res.stats["guard_recomputes"]),
-                "contexts_in_flight": nctx,
-                "quiet_shortcut": not args.no_quiet_skip,
-                "quiet_window_fraction": round(quiet_frac, 4),
-            },
-            "roofline": {
-                "kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack)",
-                "bound": "hbm",
-                "achieved": round(achieved_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "avg_kernel_ms": round(fir_avg_ms, 4),
-                "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n,
-                # the 32-tap FIR sits above the fp32 ridge (SURVEY.md hard part 1); flops
-                # of the windows that really ran the filter:
-                "fir_tflops": round(fir_tflops, 2),
-                "frac_of_fp32_valu_peak": round(fir_tflops / FP32_PEAK_TFLOPS, 4),
-            },
-            # first kernel start -> last kernel end of one capture (its latency on the device;
-            # with several contexts in flight consecutive captures overlap, so ms_per_step is smaller)
-            "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
-        }
 
-    # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) -------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle as O
-        O.build()
-        m = min(CPU_SLICE, n)
-        iq = capture[:2 * m].cpu().numpy()
-        ofir = O.load_filter_json(golden("filters", args.filter)) if flt else None
-        odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE // (flt.total_decimation if flt else 1))
-        t1 = time.perf_counter()
-        want = O.rx(iq, ofir, THRESHOLD, odev, SPB)
-        cpu_s = time.perf_counter() - t1
-        # checker: the GPU result over the same slice must be identical
-        if m == n:
-            got = res                   # the timed run's own result
+    # =====================================================================================================
+    if args.workload == "sharded":
+        # configs[4]: one capture cut into WORLD_SIZE contiguous shards, halo + carried state exchanged
+        from ookiedokie_amd.distributed import demodulate_sharded
+        n = args.samples or (1 << 32)               # per shard (configs[4]: 32 GiB per GPU; 16 GiB keeps a lease short)
+        total = n * world
+        syn = ok.Synth(dev, total, seed=SEED_BASE + 5, sample_rate=RATE)
+        shard = torch.empty(2 * n + 64, dtype=torch.int16, device="cuda")
+        syn.fill_device(shard.data_ptr(), first=rank * n, count=n, hip_device=local_rank)
+        torch.cuda.synchronize()
+        rx = receiver(n)
+        H = int(rx.halo_samples)
+        tail = shard[2 * (n - H):2 * n] if H else shard[:0]
+        comm = torch.device("cuda", local_rank) if (dist is not None and dist.get_backend() == "nccl") else None
+        if comm is None:
+            tail = tail.cpu().numpy()
+
+        def one_step():
+            if dist is None:
+                return rx.shard_begin(shard.data_ptr(), n, None, True, None)[0]
+            return demodulate_sharded(rx, d_iq_ptr=shard.data_ptr(), num_local_samples=n, tail_samples=tail,
+                                      decimated_offset=rank * n // decim, comm_device=comm)
+        res = None
+        for _ in range(max(1, args.warmup)):
+            res = one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = one_step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            st = rx.stats()
+            out = {
+                "metric": "IQ Msamples/s demodulated (SC16Q11->bits)",
+                "value": round(float(total) * args.steps / elapsed / 1e6, 1), "unit": "Msamples/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[4]-shaped: ONE capture of %d samples cut into %d contiguous shards of %d "
+                                       "samples, overlap-save halo (%d samples) + carried state machine state exchanged "
+                                       "between neighbours, fs32_fs4 FIR, p3l-nexa2012 state machine" % (total, world, n, H),
+                           "samples_per_shard": n, "shards": world, "halo_samples": H, "filter": args.filter,
+                           "device": "p3l-nexa2012", "backend": backend or "none",
+                           "state_exchange_rounds": int(getattr(res, "rounds", 0)),
+                           "parallelism": "contiguous shards, neighbour halo send/recv + all-gather of a 64-byte state"},
+                "roofline": {"kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack)", "bound": "hbm",
+                             "achieved": round(BYTES_PER_SAMPLE * n / (st["fir_kernel_ms"] * 1e-3) / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(BYTES_PER_SAMPLE * n / (st["fir_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": None, "avg_kernel_ms": round(st["fir_kernel_ms"], 4)},
+            }
+    # =====================================================================================================
+    else:
+        if args.workload == "batch":
+            n, ncaps = args.samples or BATCH_SAMPLES, BATCH_CAPTURES
+            stride = n + 64
         else:
-            chk = ok.Receiver(flt, dev, max_samples=m, threshold=THRESHOLD, samples_per_buffer=SPB,
-                              hip_device=local_rank, exact_fir=args.exact)
-            got = chk.rx_device(capture.data_ptr(), m)
-        parity = (list(got.msg_samples) == list(want.msg_samples)
-                  and bool((got.payloads == want.payloads).all())
-                  and got.stats["num_errors"] == len(want.err_samples))
-        # the same code on every core this process may use, one independent slice per thread
-        # (the reference is single-threaded, users run one capture per core)
-        from concurrent.futures import ThreadPoolExecutor
-        try:
-            ncores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            ncores = os.cpu_count() or 1
-        nthreads = max(1, min(ncores, 16))              # a one-GPU box's share of the host
-        per = m // nthreads // SPB * SPB
-        all_cores = None
-        if per > 0 and nthreads > 1:
-            slices = [iq[2 * i * per:2 * (i + 1) * per] for i in range(nthreads)]
-            t2 = time.perf_counter()
-            with ThreadPoolExecutor(nthreads) as pool:          # the ctypes call releases the GIL
-                list(pool.map(lambda x: O.rx(x, ofir, THRESHOLD, odev, SPB), slices))
-            all_s = time.perf_counter() - t2
-            all_cores = {"value": round(nthreads * per / all_s / 1e6, 2), "unit": "Msamples/s", "cores": nthreads,
-                         "sample": "%d slices of %d samples of the same capture, one thread each, %.1f s"
-                                   % (nthreads, per, all_s)}
-        cpu_model = "unknown"
-        try:
-            with open("/proc/cpuinfo") as f:
-                for line in f:
-                    if line.startswith("model name"):
-                        cpu_model = line.split(":", 1)[1].strip()
-                        break
-        except OSError:
-            pass
-        out["cpu_baseline"] = {
-            "value": round(m / cpu_s / 1e6, 2),
-            "unit": "Msamples/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": "first %d samples (%d MiB) of the same capture, oracle/ook_oracle.c "
-                      "(scalar C restatement, -O3 no FMA, 1 thread like the reference), %.1f s"
-                      % (m, m * 4 >> 20, cpu_s),
-            "host_cpu": cpu_model,
-            "host_cores": os.cpu_count(),
-            "gpu_matches_oracle_on_sample": parity,
-            "all_cores": all_cores,
-        }
-        if not parity:
-            print(json.dumps(out))
-            raise SystemExit("PARITY FAILURE: GPU result differs from the oracle on the CPU sample")
+            n, ncaps = args.samples or N_SAMPLES, 1
+            stride = n
+        # ---- synthetic captures generated directly in HBM: one (set) per context ---------------------------------
+        bufs, syns = [], []
+        for c in range(nctx):
+            if ncaps == 1:
+                b, s = synth_capture(n, SEED_BASE + 2 + 16 * rank + c)
+            else:
+                b = torch.empty(2 * stride * ncaps + 64, dtype=torch.int16, device="cuda")
+                for i in range(ncaps):
+                    s = ok.Synth(dev, n, seed=SEED_BASE + 1000 + (rank * nctx + c) * ncaps + i, sample_rate=RATE)
+                    s.fill_device(b.data_ptr() + 4 * stride * i, hip_device=local_rank)
+            bufs.append(b)
+            syns.append(s)
+        torch.cuda.synchronize()
+        kw = dict(message_capacity=1 << 18) if ncaps > 1 else {}
+        rxs = [receiver(n, ncaps, quiet_skip=not args.no_quiet_skip, **kw) for _ in range(nctx)]
+        handles = [r._h for r in rxs]
+        ptrs = [C.c_void_p(b.data_ptr()) for b in bufs]
+        for i in range(max(args.warmup, nctx)):
+            rxs[i % nctx].rx_device(bufs[i % nctx].data_ptr(), n, num_captures=ncaps, stride=stride)
+        elapsed, fir_ms, dev_ms = timed_steps(handles, ptrs, ncaps, n, stride, args.steps)
+        elapsed = max_over_ranks(elapsed)
+        res = rxs[(args.steps - 1) % nctx].result()
+
+        quiet_frac = 0.0
+        single = worst = None
+        if rank == 0 and not args.no_quiet_skip:
+            # untimed diagnostic pass: how many 512-output windows took the quiet shortcut
+            cnt = receiver(n, ncaps, count_quiet=True, **kw)
+            st = cnt.rx_device(bufs[0].data_ptr(), n, num_captures=ncaps, stride=stride).stats
+            quiet_frac = st["quiet_waves"] / max(1, st["total_waves"])
+            cnt.close()
+        if rank == 0 and world == 1 and not args.no_sub_records:
+            # ---- the same steps strictly one after the other (one context) ---------------------------------
+            k1 = max(3, min(args.steps, 10))
+            e1, f1, d1 = timed_steps(handles[:1], ptrs[:1], ncaps, n, stride, k1)
+            single = {"ms_per_step": round(e1 / k1 * 1e3, 4), "value": round(float(n) * ncaps * k1 / e1 / 1e6, 1),
+                      "unit": "Msamples/s", "steps": k1, "kernel_ms": round(float(np.mean(f1)), 4),
+                      "kernel_frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n * ncaps / (float(np.mean(f1)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "device_ms_per_step": round(float(np.mean(d1)), 4),
+                      "frac_of_hbm_read_roofline": round(float(n) * ncaps * k1 / e1 / 1e6 / (HBM_PEAK_GBS * 1e3 / 4.0), 4)}
+            # ---- worst case: every window filtered (a carrier that never drops) ---------------------------------
+            if not args.no_quiet_skip and flt is not None:
+                wrx = receiver(n, ncaps, quiet_skip=False, **kw)
+                wrx.rx_device(bufs[0].data_ptr(), n, num_captures=ncaps, stride=stride)
+                k2 = 3
+                e2, f2, _ = timed_steps([wrx._h], ptrs[:1], ncaps, n, stride, k2)
+                kms = float(np.mean(f2))
+                tf = FIR_FLOP_PER_SAMPLE * n * ncaps / (kms * 1e-3) / 1e12
+                worst = {"what": "OOKD_RX_NO_QUIET_SKIP: the filter runs on every window", "ms_per_step": round(e2 / k2 * 1e3, 4),
+                         "value": round(float(n) * ncaps * k2 / e2 / 1e6, 1), "unit": "Msamples/s", "kernel_ms": round(kms, 4),
+                         "kernel_frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n * ncaps / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "fir_tflops": round(tf, 2), "frac_of_fp32_valu_peak": round(tf / FP32_PEAK_TFLOPS, 4)}
+                wrx.close()
+        if rank == 0:
+            total_samples = float(n) * ncaps * args.steps * world
+            value = total_samples / elapsed / 1e6
+            fir_avg_ms = float(np.mean(fir_ms))
+            achieved_gbs = BYTES_PER_SAMPLE * n * ncaps / (fir_avg_ms * 1e-3) / 1e9
+            # flops actually executed: quiet windows skip the filter altogether
+            fir_tflops = FIR_FLOP_PER_SAMPLE * n * ncaps * (1.0 - quiet_frac) / (fir_avg_ms * 1e-3) / 1e12
+            traffic = None
+            prof = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(prof) and args.workload == "capture":
+                try:
+                    with open(prof) as f:
+                        tj = json.load(f)
+                    if tj.get("samples_per_launch"):
+                        traffic = tj["hbm_bytes_per_launch"] * (float(n) / tj["samples_per_launch"])
+                except Exception:
+                    traffic = None
+            if args.workload == "batch":
+                wl = ("configs[3], one GPU's share: %d independent synthetic SC16Q11 captures of %d samples (64 MiB) in ONE "
+                      "batched call per step, fs32_fs4 FIR, p3l-nexa2012 state machine" % (ncaps, n))
+            else:
+                wl = ("north_star: %d GiB synthetic SC16Q11 capture per step (%d samples), fs32_fs4 FIR, p3l-nexa2012 "
+                      "state machine, 1 MI355X per rank" % (n * 4 >> 30, n))
+            out = {
+                "metric": "IQ Msamples/s demodulated (SC16Q11->bits)",
+                "value": round(value, 1),
+                "unit": "Msamples/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "frac_of_hbm_read_roofline": round(value / world / (HBM_PEAK_GBS * 1e3 / 4.0), 4),
+                "config": {
+                    "workload": wl,
+                    "samples_per_capture": n, "captures_per_step": ncaps, "filter": args.filter,
+                    "device": "p3l-nexa2012", "sample_rate": RATE, "threshold": THRESHOLD,
+                    "samples_per_buffer": SPB, "fir_mode": "exact" if args.exact else "fma+guard-band",
+                    "parallelism": "independent captures per rank, no collective",
+                    "backend": backend or "none",
+                    "messages_per_step": int(len(res.msg_samples)),
+                    "edges_per_step": int(res.stats["num_edges"]),
+                    "fsm_path": int(res.stats["fsm_path"]),
+                    "guard_recomputes": int(res.stats["guard_recomputes"]),
+                    "contexts_in_flight": nctx,
+                    "captures_resident": nctx,
+                    "quiet_shortcut": not args.no_quiet_skip,
+                    "quiet_window_fraction": round(quiet_frac, 4),
+                },
+                "roofline": {
+                    "kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack; %d grid launches per capture)"
+                              % max(1, -(-n * ncaps // decim >> 29)),
+                    "bound": "hbm",
+                    "achieved": round(achieved_gbs, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                    "traffic": traffic,
+                    "avg_kernel_ms": round(fir_avg_ms, 4),
+                    "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n * ncaps,
+                    # the 32-tap FIR sits above the fp32 ridge (SURVEY.md hard part 1); flops
+                    # of the windows that really ran the filter:
+                    "fir_tflops": round(fir_tflops, 2),
+                    "frac_of_fp32_valu_peak": round(fir_tflops / FP32_PEAK_TFLOPS, 4),
+                },
+                # first kernel start -> last kernel end of one capture (its latency on the device;
+                # with several contexts in flight consecutive captures overlap, so ms_per_step is smaller)
+                "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
+                "single_context": single,
+                "worst_case": worst,
+            }
+
+        # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) -------------
+        if rank == 0 and world == 1 and args.workload == "capture" and not args.no_cpu_baseline:
+            import oracle as O
+            O.build()
+            m = min(CPU_SLICE, n)
+            iq = bufs[0][:2 * m].cpu().numpy()
+            ofir = O.load_filter_json(golden("filters", args.filter)) if flt else None
+            odev, _ = O.load_device_json(golden("devices", "p3l-nexa2012"), RATE // decim)
+            t1 = time.perf_counter()
+            want = O.rx(iq, ofir, THRESHOLD, odev, SPB)
+            cpu_s = time.perf_counter() - t1
+            # checker: the GPU result over the same slice must be identical
+            chk = receiver(m)
+            got = chk.rx_device(bufs[0].data_ptr(), m)
+            parity = (list(got.msg_samples) == list(want.msg_samples)
+                      and bool((got.payloads == want.payloads).all())
+                      and got.stats["num_errors"] == len(want.err_samples))
+            chk.close()
+            # the same code on every core this process may use, one independent slice per thread
+            # (SURVEY.md 8(d)(ii): the reference is single-threaded, users run one capture per core)
+            from concurrent.futures import ThreadPoolExecutor
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            nthreads = max(1, min(ncores, 512))
+            per = max(SPB, (min(1 << 24, 4 * m // nthreads)) // SPB * SPB)          # <= 2^24 samples per thread
+            all_cores = None
+            if nthreads > 1:
+                slices = [iq[2 * ((i * per) % (m - per + 1) // SPB * SPB):][:2 * per] for i in range(nthreads)]
+                t2 = time.perf_counter()
+                with ThreadPoolExecutor(nthreads) as pool:          # the ctypes call releases the GIL
+                    list(pool.map(lambda x: O.rx(x, ofir, THRESHOLD, odev, SPB), slices))
+                all_s = time.perf_counter() - t2
+                all_cores = {"value": round(nthreads * per / all_s / 1e6, 2), "unit": "Msamples/s", "cores": nthreads,
+                             "sample": "%d slices of %d samples of the same capture, one thread per core this process "
+                                       "may run on, %.1f s" % (nthreads, per, all_s)}
+            cpu_model = "unknown"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    for line in f:
+                        if line.startswith("model name"):
+                            cpu_model = line.split(":", 1)[1].strip()
+                            break
+            except OSError:
+                pass
+            out["cpu_baseline"] = {
+                "value": round(m / cpu_s / 1e6, 2),
+                "unit": "Msamples/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "first %d samples (%d MiB) of the first capture, oracle/ook_oracle.c "
+                          "(scalar C restatement, -O3 no FMA, 1 thread like the reference), %.1f s"
+                          % (m, m * 4 >> 20, cpu_s),
+                "host_cpu": cpu_model,
+                "host_cores": os.cpu_count(),
+                "gpu_matches_oracle_on_sample": parity,
+                "all_cores": all_cores,
+            }
+            if not parity:
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE: GPU result differs from the oracle on the CPU sample")
 
     if rank == 0:
         print(json.dumps(out))

@@ -583,7 +583,10 @@ class Receiver:
                     last_shard: bool, state_in: Optional[FsmState]) -> Tuple[RxResult, FsmState]:
         out = FsmState()
         hp, hn = None, 0
-        if halo is not None:
+        if halo is not None and hasattr(halo, "data_ptr"):
+            # a device (or host) tensor an RCCL recv landed in: handed over as it is, never staged through numpy
+            hp, hn = halo.data_ptr(), halo.numel() // 2
+        elif halo is not None:
             halo = np.ascontiguousarray(halo, dtype=np.int16).reshape(-1)
             hp, hn = halo.ctypes.data, halo.size // 2
         _check(lib().ookd_rx_shard_begin(self._h, d_iq_ptr, num_samples, hp, hn, int(last_shard),

@@ -47,12 +47,16 @@ def partition_captures(num_captures: int, world_size: int, rank: int) -> List[in
 def shard_bounds(num_samples: int, world_size: int, samples_per_buffer: int,
                  total_decimation: int) -> List[int]:
     """Contiguous shard boundaries, every inner one a multiple of
-    lcm(samples_per_buffer, total_decimation)."""
+    lcm(samples_per_buffer, total_decimation).  The alignment units are dealt
+    to the FIRST ranks (one more to the first ``units % world_size``), so with
+    fewer units than ranks the empty shards are the trailing ones -- they pass
+    the halo and the carried state through."""
     align = samples_per_buffer * total_decimation // math.gcd(samples_per_buffer, total_decimation)
     units = -(-num_samples // align)
+    per, extra = divmod(units, world_size)
     bounds = [0]
-    for r in range(1, world_size):
-        bounds.append(min(num_samples, (units * r // world_size) * align))
+    for r in range(world_size - 1):
+        bounds.append(min(num_samples, bounds[-1] + (per + (1 if r < extra else 0)) * align))
     bounds.append(num_samples)
     return bounds
 
@@ -81,7 +85,9 @@ def demodulate_sharded(engine, *, d_iq_ptr: int, num_local_samples: int, tail_sa
                       ``state_out`` objects expose ``bytes(state)`` and can be
                       rebuilt with ``engine.state_from_bytes``.
     tail_samples      the last ``halo_samples`` int16 I,Q samples of this shard
-                      (host array) -- what the next rank needs as FIR history.
+                      (host array, or a tensor on ``comm_device``: then the halo
+                      never leaves the device) -- what the next rank needs as
+                      FIR history.  Shorter when the shard is.
     decimated_offset  global decimated index of this shard's first output.
     comm_device       device for the tiny exchange tensors (``None`` = CPU for
                       gloo; ``torch.device('cuda', i)`` for nccl/RCCL).
@@ -94,26 +100,41 @@ def demodulate_sharded(engine, *, d_iq_ptr: int, num_local_samples: int, tail_sa
     H = int(engine.halo_samples)
 
     # ---- 1. halo: neighbour send/recv ---------------------------------------------
+    # tail_samples / the received halo stay where they are (device tensors with nccl): nothing is
+    # staged through the host.  A shard shorter than the halo (few alignment units, long filters)
+    # cannot answer before it has heard from its predecessor: its tail is the end of
+    # [received halo | own samples]; every other rank sends and receives at once.
+    def as_tensor(x):
+        if hasattr(x, "data_ptr"):
+            return x.reshape(-1)
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.int16).reshape(-1).copy())
+        return t.to(comm_device) if comm_device is not None else t
+
+    def peer(r):
+        return dist.get_global_rank(group, r) if group else r
+
     halo = None
     if H > 0 and world > 1:
-        reqs = []
-        recv_t = None
-        if rank + 1 < world:
-            send = np.ascontiguousarray(tail_samples, dtype=np.int16).reshape(-1)[-2 * H:]
-            send_t = torch.from_numpy(send.copy())
-            if comm_device is not None:
-                send_t = send_t.to(comm_device)
-            reqs.append(dist.isend(send_t, dst=dist.get_global_rank(group, rank + 1) if group else rank + 1,
-                                   group=group))
-        if rank > 0:
-            recv_t = torch.empty(2 * H, dtype=torch.int16,
-                                 device=comm_device if comm_device is not None else "cpu")
-            reqs.append(dist.irecv(recv_t, src=dist.get_global_rank(group, rank - 1) if group else rank - 1,
-                                   group=group))
-        for q in reqs:
-            q.wait()
-        if recv_t is not None:
-            halo = recv_t.cpu().numpy()
+        own = as_tensor(tail_samples)[-2 * min(H, num_local_samples):] if num_local_samples else None
+        recv_t = torch.empty(2 * H, dtype=torch.int16, device=comm_device if comm_device is not None else "cpu") \
+            if rank > 0 else None
+        if num_local_samples >= H:
+            reqs = []
+            if rank + 1 < world:
+                reqs.append(dist.isend(own.contiguous(), dst=peer(rank + 1), group=group))
+            if recv_t is not None:
+                reqs.append(dist.irecv(recv_t, src=peer(rank - 1), group=group))
+            for q in reqs:
+                q.wait()
+        else:
+            if recv_t is not None:
+                dist.recv(recv_t, src=peer(rank - 1), group=group)
+            if rank + 1 < world:
+                before = recv_t if recv_t is not None else torch.zeros(2 * H, dtype=torch.int16,
+                                                                         device=comm_device if comm_device is not None else "cpu")
+                send_t = torch.cat([before, own.to(before.device)])[-2 * H:] if own is not None else before
+                dist.send(send_t.contiguous(), dst=peer(rank + 1), group=group)
+        halo = recv_t
 
     # ---- 2. speculative pass ----------------------------------------------------------
     result, out = engine.shard_begin(d_iq_ptr, num_local_samples, halo, rank == world - 1, None)

@@ -131,7 +131,51 @@ def test_sharded_protocol_matches_sequential_chain_gloo(world, sticky):
     assert calls[0] == 1 and max(calls.values()) <= world + 1
 
 
+def _short_worker(rank, world, port, lens, out_q):
+    """shards shorter than the halo (or empty): the halo a rank hands on is the end of
+    [what it received | its own samples]"""
+    import torch.distributed as dist
+    from ookiedokie_amd import distributed as okd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = FakeEngine(rank, False)
+    start = sum(lens[:rank])
+    own = np.arange(2 * start, 2 * (start + lens[rank]), dtype=np.int16)     # sample k = (2k, 2k+1)
+    okd.demodulate_sharded(eng, d_iq_ptr=0, num_local_samples=lens[rank], tail_samples=own[-2 * eng.halo_samples:],
+                           decimated_offset=start)
+    out_q.put((rank, None if eng.halo is None else np.asarray(eng.halo).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lens", [(5, 1, 0, 4), (2, 2, 2), (7, 0, 0)])
+def test_halo_passes_through_short_and_empty_shards_gloo(lens):
+    import torch.multiprocessing as mp
+    world = len(lens)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_short_worker, args=(r, world, port, lens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    halos = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H = FakeEngine.halo_samples
+    stream = np.arange(2 * sum(lens), dtype=np.int16)
+    assert halos[0] is None
+    for r in range(1, world):
+        before = np.concatenate([np.zeros(2 * H, dtype=np.int16), stream[:2 * sum(lens[:r])]])[-2 * H:]
+        assert halos[r] == before.tolist(), (r, halos[r])
+
+
 def test_partition_and_bounds():
+    from ookiedokie_amd import distributed as okd
+    # fewer alignment units than ranks: the empty shards are the trailing ones
+    b = okd.shard_bounds(3 * 8192 - 5, 8, 8192, 1)
+    assert b == [0, 8192, 16384, 3 * 8192 - 5, 3 * 8192 - 5, 3 * 8192 - 5, 3 * 8192 - 5, 3 * 8192 - 5, 3 * 8192 - 5]
     from ookiedokie_amd import distributed as okd
     assert okd.partition_captures(10, 4, 1) == [1, 5, 9]
     assert sorted(sum((okd.partition_captures(1024, 8, r) for r in range(8)), [])) == list(range(1024))

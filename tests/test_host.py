@@ -46,10 +46,24 @@ def test_header_is_valid_c99(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors against what a C compiler makes of the header (sizes and the offsets of the
+    last members)."""
+    import subprocess
     assert C.sizeof(ok.Message) == 48
     assert C.sizeof(ok.FsmState) == 64
-    assert C.sizeof(ok.RxStats) == 88
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ookiedokie_amd.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(ookd_rx_config), sizeof(ookd_rx_stats),\n'
+                   '  sizeof(ookd_message), sizeof(ookd_fsm_state), offsetof(ookd_rx_config, pipeline_chunk_samples),\n'
+                   '  offsetof(ookd_rx_stats, pipeline_chunks)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.dirname(ok.HEADER_PATH), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    assert got == [C.sizeof(ok.RxConfig), C.sizeof(ok.RxStats), C.sizeof(ok.Message), C.sizeof(ok.FsmState),
+                   ok.RxConfig.pipeline_chunk_samples.offset, ok.RxStats.pipeline_chunks.offset]
 
 
 @pytest.mark.parametrize("name", ["fs32_fs4", "fs128_fs16_dec4", "unity1", "unity16"])
