@@ -163,6 +163,7 @@ def main():
     def timed_steps(handles, ptrs, ncaps, n, stride, steps):
         """K steps over the contexts round-robin; returns seconds and the per-step kernel / device times."""
         fir_ms, dev_ms = [], []
+        launches = [1]
         st = ok.RxStats()
         st_ref = C.byref(st)
         nctx = len(handles)
@@ -173,6 +174,7 @@ def main():
             get_stats(h, st_ref)
             fir_ms.append(st.fir_kernel_ms)
             dev_ms.append(st.total_device_ms)
+            launches[0] = max(1, st.front_launches)
 
         barrier()
         t0 = time.perf_counter()
@@ -185,7 +187,7 @@ def main():
         for k in range(max(0, steps - nctx), steps):
             finish(handles[k % nctx])
         barrier()
-        return time.perf_counter() - t0, fir_ms, dev_ms
+        return time.perf_counter() - t0, fir_ms, dev_ms, launches[0]
 
     def max_over_ranks(x):
         if dist is None:
@@ -275,7 +277,7 @@ def main():
         ptrs = [C.c_void_p(b.data_ptr()) for b in bufs]
         for i in range(max(args.warmup, nctx)):
             rxs[i % nctx].rx_device(bufs[i % nctx].data_ptr(), n, num_captures=ncaps, stride=stride)
-        elapsed, fir_ms, dev_ms = timed_steps(handles, ptrs, ncaps, n, stride, args.steps)
+        elapsed, fir_ms, dev_ms, nlaunch = timed_steps(handles, ptrs, ncaps, n, stride, args.steps)
         elapsed = max_over_ranks(elapsed)
         res = rxs[(args.steps - 1) % nctx].result()
 
@@ -290,7 +292,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_sub_records:
             # ---- the same steps strictly one after the other (one context) ---------------------------------
             k1 = max(3, min(args.steps, 10))
-            e1, f1, d1 = timed_steps(handles[:1], ptrs[:1], ncaps, n, stride, k1)
+            e1, f1, d1, _ = timed_steps(handles[:1], ptrs[:1], ncaps, n, stride, k1)
             single = {"ms_per_step": round(e1 / k1 * 1e3, 4), "value": round(float(n) * ncaps * k1 / e1 / 1e6, 1),
                       "unit": "Msamples/s", "steps": k1, "kernel_ms": round(float(np.mean(f1)), 4),
                       "kernel_frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n * ncaps / (float(np.mean(f1)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -301,7 +303,7 @@ def main():
                 wrx = receiver(n, ncaps, quiet_skip=False, **kw)
                 wrx.rx_device(bufs[0].data_ptr(), n, num_captures=ncaps, stride=stride)
                 k2 = 3
-                e2, f2, _ = timed_steps([wrx._h], ptrs[:1], ncaps, n, stride, k2)
+                e2, f2, _, _ = timed_steps([wrx._h], ptrs[:1], ncaps, n, stride, k2)
                 kms = float(np.mean(f2))
                 tf = FIR_FLOP_PER_SAMPLE * n * ncaps / (kms * 1e-3) / 1e12
                 worst = {"what": "OOKD_RX_NO_QUIET_SKIP: the filter runs on every window", "ms_per_step": round(e2 / k2 * 1e3, 4),
@@ -323,7 +325,7 @@ def main():
                     with open(prof) as f:
                         tj = json.load(f)
                     if tj.get("samples_per_launch"):
-                        traffic = tj["hbm_bytes_per_launch"] * (float(n) / tj["samples_per_launch"])
+                        traffic = tj["hbm_bytes_per_launch"] * (float(n) * ncaps / nlaunch / tj["samples_per_launch"])
                 except Exception:
                     traffic = None
             if args.workload == "batch":
@@ -363,16 +365,20 @@ def main():
                     "quiet_window_fraction": round(quiet_frac, 4),
                 },
                 "roofline": {
-                    "kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack; %d grid launches per capture)"
-                              % max(1, -(-n * ncaps // decim >> 29)),
+                    # the front end of a step goes out as `launches_per_step` grid launches of the same
+                    # kernel; the library times first start -> last end (HIP events riding on the
+                    # dispatches), so one launch lasts that / launches and moves bytes / launches
+                    "kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack)",
                     "bound": "hbm",
                     "achieved": round(achieved_gbs, 1),
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                     "traffic": traffic,
-                    "avg_kernel_ms": round(fir_avg_ms, 4),
-                    "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n * ncaps,
+                    "launches_per_step": nlaunch,
+                    "avg_kernel_ms": round(fir_avg_ms / nlaunch, 4),
+                    "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n * ncaps / nlaunch,
+                    "front_end_ms_per_step": round(fir_avg_ms, 4),
                     # the 32-tap FIR sits above the fp32 ridge (SURVEY.md hard part 1); flops
                     # of the windows that really ran the filter:
                     "fir_tflops": round(fir_tflops, 2),

@@ -50,7 +50,7 @@ int main(int argc, char **argv)
     ookd_rx *rx = NULL;
     char *text = NULL;
 
-    void *sdr = sdr_hip_file_init(&cfg);
+    void *sdr = sdr_hip_file_init((const struct ookiedokie_cfg *)&cfg);   /* same layout: see ookd_host_cfg */
     if (!sdr) return fail("sdr_hip_file_init");
 
     const void *d_iq = NULL;

@@ -238,7 +238,8 @@ typedef struct ookd_rx_stats {
     uint64_t total_waves;           /* 1024-output windows of the run (1-stage
                                        decimation-1 front end; else 0)        */
     uint32_t pipeline_chunks;       /* chunks the run was pipelined in (0 = not pipelined) */
-    uint32_t reserved;
+    uint32_t front_launches;        /* grid launches the front end went out as; fir_kernel_ms spans
+                                       first start -> last end                */
 } ookd_rx_stats;
 
 ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
@@ -473,10 +474,17 @@ typedef struct ookd_host_cfg {
     int verbosity;
 } ookd_host_cfg;
 
-void *sdr_hip_file_init(const void *cfg /* const struct ookiedokie_cfg * */);
+/* Declared with the reference's own type names (forward declarations only), so that a translation unit
+ * which also includes the reference's headers and says SDR_PROTOTYPES(hip_file) -- as sdr.c does
+ * after INTEGRATION.md section 1 -- sees the very same declarations (tests/test_boundary.py compiles
+ * exactly that).  struct complexf (src/complexf.h:31-34) and ookd_complexf are layout-identical;
+ * a host without the reference headers passes (const struct ookiedokie_cfg *)&its_ookd_host_cfg. */
+struct ookiedokie_cfg;
+struct complexf;
+void *sdr_hip_file_init(const struct ookiedokie_cfg *cfg);
 void sdr_hip_file_deinit(void *handle);
-int sdr_hip_file_rx(void *handle, ookd_complexf *samples, unsigned int count);
-int sdr_hip_file_tx(void *handle, const ookd_complexf *samples,
+int sdr_hip_file_rx(void *handle, struct complexf *samples, unsigned int count);
+int sdr_hip_file_tx(void *handle, const struct complexf *samples,
                     unsigned int count);
 int sdr_hip_file_flush(void *handle);
 /* Extra, beyond the vtable: the whole capture as a device pointer

@@ -109,7 +109,7 @@ class RxStats(C.Structure):
         ("fsm_path", C.c_uint32), ("fsm_fallback_reason", C.c_uint32),
         ("fir_kernel_ms", C.c_float), ("total_device_ms", C.c_float),
         ("quiet_waves", C.c_uint64), ("total_waves", C.c_uint64),
-        ("pipeline_chunks", C.c_uint32), ("reserved", C.c_uint32),
+        ("pipeline_chunks", C.c_uint32), ("front_launches", C.c_uint32),
     ]
 
 

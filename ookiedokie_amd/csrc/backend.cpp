@@ -54,9 +54,10 @@ extern "C" {
 
 void sdr_hip_file_deinit(void *handle) { delete static_cast<HipFile *>(handle); }
 
-void *sdr_hip_file_init(const void *cfg_v) {
+void *sdr_hip_file_init(const struct ookiedokie_cfg *cfg_v) {
     clear_error();
-    const ookd_host_cfg *cfg = static_cast<const ookd_host_cfg *>(cfg_v);
+    // same layout as the reference's struct (tests/test_boundary.py asserts the offsets against its header)
+    const ookd_host_cfg *cfg = reinterpret_cast<const ookd_host_cfg *>(cfg_v);
     if (!cfg || !cfg->sdr_args || cfg->samples_per_buffer == 0) {
         set_error("A filename must be provided as \"SDR args\" when using hip_file.");
         return nullptr;
@@ -89,7 +90,8 @@ void *sdr_hip_file_init(const void *cfg_v) {
     return h.release();
 }
 
-int sdr_hip_file_rx(void *handle, ookd_complexf *samples, unsigned int count) {
+int sdr_hip_file_rx(void *handle, struct complexf *samples_v, unsigned int count) {
+    ookd_complexf *samples = reinterpret_cast<ookd_complexf *>(samples_v);
     HipFile *h = static_cast<HipFile *>(handle);
     if (!h || !h->rx || !samples) return -1;
     int status = 0;
@@ -116,7 +118,8 @@ int sdr_hip_file_rx(void *handle, ookd_complexf *samples, unsigned int count) {
     return status;
 }
 
-int sdr_hip_file_tx(void *handle, const ookd_complexf *samples, unsigned int count) {
+int sdr_hip_file_tx(void *handle, const struct complexf *samples_v, unsigned int count) {
+    const ookd_complexf *samples = reinterpret_cast<const ookd_complexf *>(samples_v);
     HipFile *h = static_cast<HipFile *>(handle);
     if (!h || h->rx || !samples) return -1;
     std::vector<int16_t> buf(2 * (size_t)h->buf_len);

@@ -291,6 +291,7 @@ struct ookd_rx {
     const void *last_iq = nullptr;  // arguments of the last run (a refused pipelined run is redone whole)
     uint64_t last_stride = 0;
     bool no_pipeline_once = false;
+    uint32_t front_launches = 1;    // of the last run
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
     uint32_t stream_waves = 12;     // persistent front-end waves per CU
     uint64_t front_launch_outputs = 1ull << 29;    // decimated samples per front-end grid launch (all captures together)
@@ -763,6 +764,7 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
         ctl.num_caps = run_caps;
         ctl.waves_per_cu = stream_waves;
         ctl.static_stride = getenv("OOKD_STREAM_STRIDE") ? 1u : 0u;
+        front_launches = 1;
         HIPCHK(launch_front_stream(fp, ctl, exact, false, stream, ev[0], ev[1]));
     } else {
         // The tuned kernels go out as several grid launches of front_launch_tiles wave tiles: while a
@@ -775,7 +777,9 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
         const uint64_t tiles = tile_bits ? (uint64_t)fp.tiles_per_cap : 0;
         const uint64_t per = tile_bits ? std::max<uint64_t>(1, front_launch_outputs / tile_bits / std::max(1u, run_caps)) : 0;
         auto launch_all = [&]() -> hipError_t {
+            front_launches = 1;
             if (!tile_bits || tiles <= per + per / 2) return launch_front(fp, run_caps, exact, stream, ev[0], ev[1]);
+            front_launches = (uint32_t)((tiles + per - 1) / per);
             for (uint64_t t = 0; t < tiles; t += per) {
                 const bool first = t == 0, last = t + per >= tiles;
                 const hipError_t e = launch_front(fp, run_caps, exact, stream, first ? ev[0] : nullptr,
@@ -1085,6 +1089,7 @@ int ookd_rx::collect_results() {
     if (!chunks.empty()) {
         // pipelined: the front-end kernels of all chunks; first kernel start -> last kernel end
         stats.pipeline_chunks = (uint32_t)chunks.size();
+        stats.front_launches = (uint32_t)chunks.size();
         float sum = 0.0f;
         for (size_t c = 0; c < chunks.size(); ++c) {
             if (hipEventElapsedTime(&ms, ev_c0[c], ev_c1[c]) == hipSuccess) sum += ms;
@@ -1092,6 +1097,7 @@ int ookd_rx::collect_results() {
         stats.fir_kernel_ms = sum;
         if (hipEventElapsedTime(&ms, ev_c0[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
     } else {
+        stats.front_launches = front_launches;
         if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) stats.fir_kernel_ms = ms;
         if (hipEventElapsedTime(&ms, ev[0], ev[2]) == hipSuccess) stats.total_device_ms = ms;
     }

@@ -691,6 +691,37 @@ def test_fir_impulse_known_answers(ok, oracle):
     assert list(np.nonzero(y[:, 0])[0]) == list(range(49, 65))
 
 
+@pytest.mark.parametrize("name", ["fs32_fs4", "fs128_fs16_dec4"])
+@pytest.mark.parametrize("period", [4.0, 32.0])
+def test_fir_harness_tones_steady_state(ok, name, period):
+    """src/matlab/gen_samples.m:19-34 on the GPU FIR: behind the start-up the output is H(w) * tone, a
+    known answer independent of any restatement of the filter loop (1e-5 of sum|h|)."""
+    from tests.helpers import harness_tone, steady_state_response
+    f = _flt(ok, name)
+    x = harness_tone(400000, period)
+    fir = ok.StreamFir(f, 65536)             # fed like the reference feeds fir_filter_and_decimate: max_input at a time
+    y = np.concatenate([fir.filter_and_decimate(x[i:i + 65536]) for i in range(0, x.shape[0], 65536)])
+    taps = [f.stage(s)[1] for s in range(f.num_stages)]
+    decs = [f.stage(s)[0] for s in range(f.num_stages)]
+    want, first = steady_state_response(taps, decs, x.shape[0], period)
+    assert y.shape[0] == want.size
+    got = y[:, 0].astype(np.float64) + 1j * y[:, 1].astype(np.float64)
+    tol = 1e-5 * float(np.prod([np.abs(t).sum() for t in taps]))
+    assert np.abs(got[first + 64:] - want[first + 64:]).max() <= tol
+
+
+def test_fir_harness_long_impulse(ok):
+    # gen_samples.m:13-16: 10^6 samples, impulse at sample 1000
+    x = np.zeros((1000000, 2), np.float32)
+    x[999, 0] = 1.0
+    f = _flt(ok, "fs32_fs4")
+    fir = ok.StreamFir(f, 65536)
+    y = np.concatenate([fir.filter_and_decimate(x[i:i + 65536]) for i in range(0, x.shape[0], 65536)])
+    _, taps = f.stage(0)
+    assert (y[999:1031, 0].view(np.uint32) == taps.view(np.uint32)).all()
+    assert not y[:999].any() and not y[1031:].any()
+
+
 def test_backend_rx_matches_file_backend_semantics(ok, oracle, vectors, tmp_path):
     g, iq = _g1(vectors, noise_seed=41)
     iq = iq[:2 * 20000].copy()

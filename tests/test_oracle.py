@@ -12,7 +12,7 @@ Sources of truth, strongest first:
 import numpy as np
 import pytest
 
-from tests.helpers import edges_of, golden_path, iq_from_rle, stream_from_runs
+from tests.helpers import harness_tone, steady_state_response, edges_of, golden_path, iq_from_rle, stream_from_runs
 
 RATE = 3000000
 
@@ -116,6 +116,47 @@ def test_fir_dec4_matches_numpy_restatement(oracle, chunk):
     s1 = np_fir_sequential(_impulse(), f.stage_taps(0), 2)
     s2 = np_fir_sequential(s1, f.stage_taps(1), 2)
     assert (y.view(np.uint32) == s2.view(np.uint32)).all()
+
+
+def test_fir_long_impulse_returns_taps_exactly(oracle):
+    # gen_samples.m:13-16: 10^6 samples, impulse at sample 1000 (index 999)
+    f = _fir(oracle, "fs32_fs4")
+    y = oracle.fir_run(f, _impulse(n=1000000, at=999), 8192)
+    assert (y[999:1031, 0].view(np.uint32) == f.taps.view(np.uint32)).all()
+    assert not y[:999].any() and not y[1031:].any()
+
+
+@pytest.mark.parametrize("name", ["fs32_fs4", "fs128_fs16_dec4", "unity16"])
+@pytest.mark.parametrize("period", [4.0, 32.0])
+def test_fir_tone_steady_state_is_the_frequency_response(oracle, name, period):
+    """gen_samples.m:19-34 (tones at Fs/4 and Fs/32, 10^6 samples): behind the start-up the output is
+    H(w) * tone -- a known answer that does not come from any restatement of the filter loop.
+    Tolerance: float32 accumulation over T taps, 1e-5 of sum|h| (the north_star's FIR tolerance)."""
+    f = _fir(oracle, name)
+    x = harness_tone(1000000, period)
+    y = oracle.fir_run(f, x, 8192)
+    taps = [f.stage_taps(s) for s in range(f.num_stages)]
+    decs = [int(d) for d in f.decimation]
+    want, first = steady_state_response(taps, decs, x.shape[0], period)
+    assert y.shape[0] == want.size
+    tol = 1e-5 * float(np.prod([np.abs(t).sum() for t in taps]))
+    got = y[:, 0].astype(np.float64) + 1j * y[:, 1].astype(np.float64)
+    assert np.abs(got[first + 64:] - want[first + 64:]).max() <= tol
+    # fs32_fs4 passes Fs/32 and stops Fs/4 (filters/README.md: cutoff Fs/4... the name says it)
+    if name == "fs32_fs4":
+        mag = np.abs(got[2000:]).mean()
+        assert (mag > 0.9) if period == 32.0 else (mag < 0.05)
+
+
+def test_fir_two_tone_is_the_sum_of_the_tones(oracle):
+    # gen_samples.m:36-38: (tone_fs4 + tone_fs32) / 2
+    f = _fir(oracle, "fs32_fs4")
+    x = (harness_tone(200000, 4.0).astype(np.float64) + harness_tone(200000, 32.0)) / 2.0
+    y = oracle.fir_run(f, x.astype(np.float32), 4096)
+    w4, first = steady_state_response([f.taps], [1], 200000, 4.0)
+    w32, _ = steady_state_response([f.taps], [1], 200000, 32.0)
+    got = y[:, 0].astype(np.float64) + 1j * y[:, 1].astype(np.float64)
+    assert np.abs(got[first + 64:] - (w4 + w32)[first + 64:] / 2.0).max() <= 1e-5 * float(np.abs(f.taps).sum())
 
 
 def test_fir_noisy_signal_bit_identical_to_numpy_restatement(oracle, vectors):
