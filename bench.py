@@ -150,9 +150,11 @@ def main():
     L = ok.lib()
     submit, wait, get_stats = L.ookd_rx_submit_device, L.ookd_rx_wait, L.ookd_rx_get_stats
 
+    gate = ok.FrontGate()           # the contexts of this process take turns for their front ends
+
     def receiver(n, caps=1, **kw):
         return ok.Receiver(flt, dev, max_samples=n, max_captures=caps, threshold=THRESHOLD, samples_per_buffer=SPB,
-                           hip_device=local_rank, exact_fir=args.exact, **kw)
+                           hip_device=local_rank, exact_fir=args.exact, front_gate=gate, **kw)
 
     def synth_capture(n, seed):
         syn = ok.Synth(dev, n, seed=seed, sample_rate=RATE)

@@ -177,6 +177,15 @@ enum {
     OOKD_RX_NO_PIPELINE = 1u << 7
 };
 
+/* Contexts created with the same gate (and on the same device) queue their front-end kernels one
+ * after the other instead of side by side: the front end is HBM bound, two at once only slow each
+ * other down, while the latency-bound edges / state machine of one capture do overlap the next
+ * context's front end.  For hosts that keep several captures in flight (bench.py does).  The gate
+ * must outlive the contexts that use it; contexts without one never wait for anybody. */
+typedef struct ookd_rx_gate ookd_rx_gate;
+ookd_rx_gate *ookd_rx_gate_create(void);
+void ookd_rx_gate_destroy(ookd_rx_gate *gate);
+
 typedef struct ookd_rx_config {
     int32_t hip_device;             /* ordinal, e.g. LOCAL_RANK               */
     uint32_t flags;                 /* OOKD_RX_*                              */
@@ -195,6 +204,7 @@ typedef struct ookd_rx_config {
                                        chunk c, the state machine's state carried from chunk to chunk in
                                        device memory (results identical).  0 = never (the default: on
                                        this runtime the chunked run is slower)          */
+    ookd_rx_gate *front_gate;       /* shared front-end gate (see above), NULL = none */
 } ookd_rx_config;
 
 typedef struct ookd_message {

@@ -82,7 +82,7 @@ class RxConfig(C.Structure):
         ("max_captures", C.c_uint32), ("edge_capacity", C.c_uint64),
         ("segment_buffers", C.c_uint32), ("message_slots", C.c_uint32),
         ("message_capacity", C.c_uint64), ("stream", C.c_void_p),
-        ("pipeline_chunk_samples", C.c_uint64),
+        ("pipeline_chunk_samples", C.c_uint64), ("front_gate", C.c_void_p),
     ]
 
 
@@ -207,6 +207,8 @@ _PROTOTYPES = {
                                        C.c_char_p, C.c_size_t]),
     "ookd_print_messages": (C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_uint64,
                                          C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "ookd_rx_gate_create": (C.c_void_p, []),
+    "ookd_rx_gate_destroy": (None, [C.c_void_p]),
     "sdr_hip_file_init": (C.c_void_p, [C.c_void_p]),
     "sdr_hip_file_deinit": (None, [C.c_void_p]),
     "sdr_hip_file_rx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint]),
@@ -504,6 +506,27 @@ class RxResult:
         return RxResult(self.captures[m], self.msg_samples[m], self.payloads[m], self.stats)
 
 
+class FrontGate:
+    """Contexts created with the same gate take turns for their (HBM-bound) front-end kernels
+    (ookd_rx_gate_create); pass it to every Receiver that should."""
+
+    def __init__(self):
+        self._h = lib().ookd_rx_gate_create()
+        if not self._h:
+            raise OokdError(-3, "ookd_rx_gate_create failed")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().ookd_rx_gate_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Receiver:
     """Fused replacement of the reference rx loop body for whole captures in HBM."""
 
@@ -514,7 +537,8 @@ class Receiver:
                  edge_capacity: int = 0, segment_buffers: int = 0, message_slots: int = 0,
                  message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
                  quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False,
-                 front_grid: bool = False, pipeline: bool = True, pipeline_chunk_samples: int = 0):
+                 front_grid: bool = False, pipeline: bool = True, pipeline_chunk_samples: int = 0,
+                 front_gate: Optional["FrontGate"] = None):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
@@ -531,6 +555,8 @@ class Receiver:
         cfg.message_capacity = message_capacity
         cfg.stream = stream
         cfg.pipeline_chunk_samples = pipeline_chunk_samples
+        cfg.front_gate = front_gate._h if front_gate is not None else None
+        self._gate = front_gate         # keeps it alive as long as the context
         self._filter, self._device = filt, device
         self.payload_bytes = device.payload_bytes if device else 0
         self.total_decimation = filt.total_decimation if filt else 1

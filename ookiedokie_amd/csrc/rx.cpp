@@ -59,20 +59,20 @@ struct Chunk {
 constexpr uint64_t kPipeDefaultChunk = 1ull << 28;      // input samples
 constexpr uint64_t kPipeTailChunk = 1ull << 25;         // the last chunks shrink down to this: a short exposed chain
 
-// Front-end kernels of different contexts on one device take turns: they are
-// HBM bound, so running two at once only makes both slower, while everything
-// after them (edges, state machine: latency bound) overlaps the next
-// context's front end.  Per device the stop event of the front-end kernel queued
-// last is remembered (it rides on that kernel's dispatch: launch_front); a context
-// makes its stream wait for it before launching its own -- no marker packets.
-constexpr int kMaxGateDevices = 64;
-std::atomic<int> g_live_contexts[kMaxGateDevices];
+}  // namespace
 
-struct FrontGate {
+// Front-end kernels of contexts that share a gate take turns: they are HBM bound, so running two
+// at once only makes both slower, while everything after them (edges, state machine: latency
+// bound) overlaps the next context's front end.  The gate remembers the stop event of the
+// front-end launch queued last (it rides on that kernel's dispatch: launch_front); a context
+// makes its stream wait for it before launching its own -- no marker packets.  An explicit
+// object handed to ookd_rx_create by the caller: there is no process-wide state.
+struct ookd_rx_gate {
     std::mutex m;
-    hipEvent_t last[kMaxGateDevices] = {};
+    hipEvent_t last = nullptr;
 };
-FrontGate g_gate;
+
+namespace {
 
 template <typename T>
 struct DevBuf {
@@ -365,12 +365,11 @@ struct ookd_rx {
     uint32_t final_parity = 0;
     ookd_rx_stats stats{};
 
-    bool counted = false;           // this context is in g_live_contexts
+    ookd_rx_gate *gate = nullptr;   // shared with other contexts by the caller, or null
     ~ookd_rx() {
-        if (counted && dev >= 0 && dev < kMaxGateDevices) g_live_contexts[dev].fetch_sub(1);
-        if (dev >= 0 && dev < kMaxGateDevices) {
-            std::lock_guard<std::mutex> lock(g_gate.m);
-            if (g_gate.last[dev] == ev[1]) g_gate.last[dev] = nullptr;      // ev[1] is destroyed below
+        if (gate) {
+            std::lock_guard<std::mutex> lock(gate->m);
+            if (gate->last == ev[1]) gate->last = nullptr;      // ev[1] is destroyed below
         }
         (void)hipSetDevice(dev);
         d_taps.release();
@@ -788,15 +787,14 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
             }
             return hipSuccess;
         };
-        if (dev >= 0 && dev < kMaxGateDevices && g_live_contexts[dev].load() > 1) {
-            // front ends of different contexts take turns (HBM bound: two at once only slow each other);
+        if (gate) {
             // wait + launch + publish under the lock: the event must be on its way before another
             // context may wait for it
-            std::lock_guard<std::mutex> lock(g_gate.m);
-            hipEvent_t prev = g_gate.last[dev];
+            std::lock_guard<std::mutex> lock(gate->m);
+            hipEvent_t prev = gate->last;
             if (prev && prev != ev[1]) HIPCHK(hipStreamWaitEvent(stream, prev, 0));
             HIPCHK(launch_all());
-            g_gate.last[dev] = ev[1];
+            gate->last = ev[1];
         } else {
             HIPCHK(launch_all());
         }
@@ -1493,14 +1491,15 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             return nullptr;
         }
     }
-    if (rx->dev >= 0 && rx->dev < kMaxGateDevices) {
-        g_live_contexts[rx->dev].fetch_add(1);
-        rx->counted = true;
-    }
+    rx->gate = static_cast<ookd_rx_gate *>(cfg->front_gate);
     return rx.release();
 }
 
 void ookd_rx_destroy(ookd_rx *rx) { delete rx; }
+
+ookd_rx_gate *ookd_rx_gate_create(void) { return new (std::nothrow) ookd_rx_gate(); }
+
+void ookd_rx_gate_destroy(ookd_rx_gate *gate) { delete gate; }
 
 int ookd_rx_submit_device(ookd_rx *rx, const void *d_iq, uint32_t num_captures,
                           uint64_t samples_per_capture, uint64_t capture_stride_samples) {

@@ -919,8 +919,9 @@ def test_submit_wait_two_contexts(ok, oracle, vectors):
     want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, _odev(oracle, "p3l-nexa2012"), 8192)
     n = iq.size // 2
     t = torch.from_numpy(iq.copy()).cuda()
-    a = ok.Receiver(f, d, max_samples=n)
-    b = ok.Receiver(f, d, max_samples=n)
+    gate = ok.FrontGate()               # the two contexts take turns for their front ends
+    a = ok.Receiver(f, d, max_samples=n, front_gate=gate)
+    b = ok.Receiver(f, d, max_samples=n, front_gate=gate)
     with pytest.raises(ok.OokdError):
         a.wait()                            # nothing submitted
     for _ in range(3):

@@ -4,7 +4,8 @@ files under profiles/:
 
     python tools/summarize_profiles.py r01
 
-  <round>_kernel_stats.csv       rocprofv3 --kernel-trace --stats summary
+  <round>_kernel_stats.csv       rocprofv3 --kernel-trace --stats summary of the default bench command
+  <round>_kernel_stats_one_context.csv   the same with --contexts 1 (every kernel undisturbed)
   traffic.json                   HBM bytes per launch of the front-end kernel
                                  (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes)
   <round>_bench_line*.json       the bench lines of the same build
@@ -18,7 +19,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "fir1_bits_kernel"
-ALGO_BYTES = 4.125 * (1 << 28)
+SAMPLES_PER_LAUNCH = 1 << 29          # the front end of a 2^32-sample capture goes out as 8 grid launches
+ALGO_BYTES = 4.125 * SAMPLES_PER_LAUNCH
 
 
 def counter_avg(dirname, counter):
@@ -48,16 +50,19 @@ def main():
             json.dump({
                 "kernel": "ookd::" + KERNEL + "<false>",
                 "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python "
-                           "bench.py --steps 5 --warmup 1 --no-cpu-baseline (two separate passes, "
+                           "bench.py --steps 4 --warmup 1 --contexts 1 --no-cpu-baseline --no-sub-records (two separate passes, "
                            "tools/collect_profiles.sh)",
                 "FETCH_SIZE_KB_avg": fetch, "WRITE_SIZE_KB_avg": write, "launches": [nf, nw],
                 "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane streaming reads "
                               "-> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": ALGO_BYTES,
+                "samples_per_launch": SAMPLES_PER_LAUNCH,
             }, f, indent=1)
         print("traffic: %.4f GB per launch (algorithmic %.4f GB)" % (hbm / 1e9, ALGO_BYTES / 1e9))
-    for name in ("bench_line", "bench_line_no_quiet_skip", "bench_line_dec4", "bench_line_one_context",
-                 "bench_line_two_contexts"):
+    stats1 = sorted(glob.glob(os.path.join(src, "stats1", "*", "*kernel_stats.csv")), key=os.path.getmtime)
+    if stats1:
+        shutil.copy(stats1[-1], os.path.join(dst, rnd + "_kernel_stats_one_context.csv"))
+    for name in ("bench_line", "bench_line_dec4", "bench_line_batch", "bench_line_1GiB"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p):
             with open(p) as f:
