@@ -313,6 +313,26 @@ def main():
                          "kernel_frac_of_hbm_peak": round(BYTES_PER_SAMPLE * n * ncaps / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "fir_tflops": round(tf, 2), "frac_of_fp32_valu_peak": round(tf / FP32_PEAK_TFLOPS, 4)}
                 wrx.close()
+        fallback = None
+        if rank == 0 and world == 1 and not args.no_sub_records and ncaps == 1:
+            # ---- what a capture costs when the scan form refuses it: the round form, on a 1 GiB slice ---------
+            m = min(n, 1 << 28)
+            frx = receiver(m, fsm_rounds=True)
+            srx = receiver(m)
+            for r_ in (frx, srx):
+                r_.rx_device(bufs[0].data_ptr(), m)
+            t0 = time.perf_counter()
+            frx.process_device(bufs[0].data_ptr(), m)
+            t_rounds = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            srx.process_device(bufs[0].data_ptr(), m)
+            t_scan = time.perf_counter() - t0
+            fallback = {"what": "the state machine's round form (what a capture costs when the scan form refuses it), "
+                                "one call over the first %d samples" % m,
+                        "rounds_ms": round(t_rounds * 1e3, 4), "scan_ms": round(t_scan * 1e3, 4),
+                        "fix_point_rounds": int(frx.stats()["fsm_iterations"])}
+            frx.close()
+            srx.close()
         if rank == 0:
             total_samples = float(n) * ncaps * args.steps * world
             value = total_samples / elapsed / 1e6
@@ -391,6 +411,7 @@ def main():
                 "device_ms_per_step": round(float(np.mean(dev_ms)), 4),
                 "single_context": single,
                 "worst_case": worst,
+                "fallback_path": fallback,
             }
 
         # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) -------------

@@ -482,6 +482,9 @@ struct ScanParams {
     uint64_t pos_origin;        // the chunk's first decimated sample: added to message / error positions
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device), or null = 0
     const uint32_t *edge_overflow;      // the edge stage's overflow flag: the scan refuses such a run
+    uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
+                                // capture whose path leaves the model is left out of the results -- the host
+                                // redoes it alone in the round form -- instead of voiding the whole call
     SegState *final_state;
     uint32_t *fallback;
     uint32_t total_blocks_cap;
@@ -936,6 +939,16 @@ __device__ __forceinline__ void locate_block(const ScanParams &sp, uint32_t gb, 
     }
     cap = lo;
     lb = gb - sp.cap_block_off[lo];
+}
+
+// capture `cap` cannot be decoded by the scan: per capture in a batched run, else the whole call
+__device__ __forceinline__ void scan_refuse(const ScanParams &sp, uint32_t cap, uint32_t reason) {
+    if (sp.cap_fallback && sp.f.num_captures > 1) {
+        atomicOr(&sp.cap_fallback[cap], reason);
+        atomicOr(sp.f.flags, 2u);               // bit 1 of the header flags: some capture was refused
+    } else {
+        atomicOr(sp.fallback, reason);
+    }
 }
 
 // the concrete incoming state: reset, the host's (shards), or the chunk before's (pipelined runs)
@@ -1428,13 +1441,13 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 Acc a;
                 bool alive = true;
                 if (in == code_poison(T)) {
-                    atomicOr(sp.fallback, (uint32_t)kFbPoison);
+                    scan_refuse(sp, cap, (uint32_t)kFbPoison);
                     acc_init(a);
                     f.cur = f.nbits = f.k = f.prev = 0;
                 } else {
                     const Span span = span_entered(T, edges, i, in);       // stuck: from where it was normal
                     alive = run_leaf(T, in, span, s_resume[l], f, a);
-                    if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                    if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                 }
                 write_event(events[i], a, f, alive);
             }
@@ -1450,7 +1463,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 PSim f;
                 Acc a;
                 const bool alive = first_leaf(T, sp, edges, ne, f, a);
-                if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                 write_event(events[0], a, f, alive);
             }
             if (threadIdx.x == 64 && ne > 0) {
@@ -1485,12 +1498,12 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 Acc a;
                 bool alive = true;
                 if (in == code_poison(T)) {
-                    atomicOr(sp.fallback, (uint32_t)kFbPoison);
+                    scan_refuse(sp, cap, (uint32_t)kFbPoison);
                     acc_init(a);
                     f.cur = f.nbits = f.k = f.prev = 0;
                 } else {
                     alive = run_leaf(T, in, tail, next_buffer_start(T, edges[ne - 1]), f, a);
-                    if (a.overflow) atomicOr(sp.fallback, (uint32_t)kFbOverflow);
+                    if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                 }
                 write_event(events[ne], a, f, alive);
             }
@@ -1572,7 +1585,7 @@ __device__ void fin_block_scan(const ScanParams &sp, uint32_t cap, uint32_t fb, 
     uint64_t e0;
     const uint64_t ne = cap_edges(sp.f, cap, e0);
     const uint64_t i = (uint64_t)fb * kFinBlock + threadIdx.x;
-    L.have = i <= ne;
+    L.have = i <= ne && !(sp.cap_fallback && sp.f.num_captures > 1 && sp.cap_fallback[cap]);
     if (L.have) L.ev = sp.events[e0 + cap + i];
     uint32_t a = L.have ? L.ev.napp : 0u, o = L.have ? L.ev.nout : 0u, e = L.have ? L.ev.nerr : 0u;
     const uint32_t na = a, no = o, nerr = e;
@@ -2186,6 +2199,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.pos_origin = a.pos_origin;
     sp.totals_in = a.totals_in;
     sp.edge_overflow = a.edge_overflow;
+    sp.cap_fallback = a.cap_fallback;
     sp.final_state = a.final_state;
     sp.fallback = a.fallback;
     sp.total_blocks_cap = a.total_blocks_cap;

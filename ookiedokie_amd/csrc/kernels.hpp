@@ -279,6 +279,7 @@ struct FsmScanArgs {
     uint64_t pos_origin;        // the chunk's first decimated sample
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device)
     const uint32_t *edge_overflow;      // the edge stage's overflow flag (device), or null
+    uint32_t *cap_fallback;     // [captures] per-capture refusal bits (zero at launch), or null
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]

@@ -292,6 +292,9 @@ struct ookd_rx {
     uint64_t last_stride = 0;
     bool no_pipeline_once = false;
     uint32_t front_launches = 1;    // of the last run
+    DevBuf<uint32_t> d_cap_fallback;        // [captures] the scan's per-capture refusal bits (batched runs)
+    std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
+    bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
     uint32_t stream_waves = 12;     // persistent front-end waves per CU
     uint64_t front_launch_outputs = 1ull << 29;    // decimated samples per front-end grid launch (all captures together)
@@ -381,6 +384,7 @@ struct ookd_rx {
         d_ctl.release();
         d_quiet.release();
         d_carry.release();
+        d_cap_fallback.release();
         d_chunk_totals.release();
         d_fin_tickets.release();
         for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
@@ -531,7 +535,8 @@ struct ookd_rx {
     int prepare_front(FrontParams &fp);
     int run_state_machine(const FsmStateDev *first, bool fresh);
     int fsm_scan(const FsmStateDev *first);
-    int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first);
+    int fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first, const FsmParams *view = nullptr);
+    int redo_refused_captures();
     int fetch_results();
     int enqueue_publish();
     PublishParams publish_params() const;
@@ -805,12 +810,13 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
 
 // Runs segment-parallel state machine rounds until no segment's incoming
 // state changes.  fresh: (re)initialise every segment's assumed state.
-int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first) {
+// view: the geometry to run on instead of the whole run's (one capture of a batch: redo_refused_captures)
+int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_first, const FsmParams *view) {
     if (!have_fsm || run_n_out == 0) {
         HIPCHK(hipEventRecord(ev[2], stream));
         return OOKD_OK;
     }
-    const FsmParams fp = fsm_params();
+    const FsmParams fp = view ? *view : fsm_params();
     if (fresh) {
         HIPCHK(launch_fsm_prepare(fp, first, stream));
         iter_next = 0;
@@ -848,12 +854,14 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
             if (incremental && h_hdr->changed[i] == 0) conv = true;
         }
         if (conv) break;
-        if (rounds > kMaxIter) {
+        // every round settles at least one more segment's incoming state, left to right: a capture of
+        // S segments is through after at most S + 1 rounds -- more would be a bug, not a hard input
+        if (rounds > std::max<uint32_t>(kMaxIter, fp.num_captures * fp.segs_per_cap + 2 * kIterBatch)) {
             set_error("state machine fix-point did not converge in %u rounds", rounds);
             return OOKD_ERR_ARG;
         }
     }
-    if (d_debug.p) {
+    if (d_debug.p && !view) {
         const size_t nseg = (size_t)run_caps * run_segs_per_cap;
         std::vector<uint64_t> dbg(nseg * 4);
         HIPCHK(hipMemcpy(dbg.data(), d_debug.p, dbg.size() * 8, hipMemcpyDeviceToHost));
@@ -874,7 +882,80 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
     final_parity = (iter_next - 1) & 1u;
     stats.fsm_iterations = rounds;
     HIPCHK(launch_fsm_gather(fp, stream));
-    HIPCHK(hipEventRecord(ev[2], stream));
+    if (!view) HIPCHK(hipEventRecord(ev[2], stream));
+    return OOKD_OK;
+}
+
+// A batched run in which the scan refused some captures (their path left its model): the scan's
+// results for all the others stand; each refused capture is redone alone in the round form and
+// its messages / errors are merged in, in capture order.  (Round 1 sent the whole call -- every
+// capture of the batch -- through the rounds.)
+int ookd_rx::redo_refused_captures() {
+    std::vector<uint32_t> flags(run_caps);
+    HIPCHK(hipMemcpy(flags.data(), d_cap_fallback.p, run_caps * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
+    const uint64_t total = std::min<uint64_t>(h_hdr->totals[0], msg_capacity);
+    std::vector<MsgDev> merged(h_msgs, h_msgs + std::min(total, first));
+    if (total > first) {
+        merged.resize(total);
+        HIPCHK(hipMemcpy(merged.data() + first, d_msgs.p + first, (total - first) * sizeof(MsgDev), hipMemcpyDeviceToHost));
+    }
+    mixed_errs.resize(std::min<uint64_t>(h_hdr->totals[1], d_scan_errs.n));
+    if (!mixed_errs.empty()) {
+        HIPCHK(hipMemcpy(mixed_errs.data(), d_scan_errs.p, mixed_errs.size() * 8, hipMemcpyDeviceToHost));
+    }
+    uint64_t nerr = h_hdr->totals[1];
+    uint32_t reasons = 0, rounds = 0;
+    for (uint32_t cap = 0; cap < run_caps; ++cap) {
+        if (!flags[cap]) continue;
+        reasons |= flags[cap];
+        FsmParams one = fsm_params();
+        one.bits += (size_t)cap * run_words;
+        one.blk_offset += (size_t)cap * run_blocks;     // (its entries are offsets into the one edge list)
+        one.num_captures = 1;
+        HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+        int rc = fsm_to_fixpoint(nullptr, true, false, &one);
+        if (rc != OOKD_OK) return rc;
+        rounds += stats.fsm_iterations;
+        ResultHeader hdr;
+        HIPCHK(hipMemcpy(&hdr, d_hdr.p, sizeof(hdr), hipMemcpyDeviceToHost));
+        if (hdr.flags & 1u) {
+            set_error("a state machine segment produced more than %u messages "
+                      "(raise ookd_rx_config.message_slots)", msg_slots);
+            return OOKD_ERR_CAPACITY;
+        }
+        const uint64_t m = std::min<uint64_t>(hdr.totals[0], msg_capacity);
+        const size_t at = merged.size();
+        merged.resize(at + m);
+        if (m) HIPCHK(hipMemcpy(merged.data() + at, d_msgs.p, m * sizeof(MsgDev), hipMemcpyDeviceToHost));
+        for (size_t i = at; i < merged.size(); ++i) merged[i].capture = cap;
+        // its errors, from the per-segment lists
+        const size_t nseg = run_segs_per_cap;
+        std::vector<uint32_t> counts(nseg);
+        std::vector<uint64_t> errs(nseg * err_slots);
+        HIPCHK(hipMemcpy(counts.data(), d_seg_err_count.p, nseg * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(errs.data(), d_seg_errs.p, errs.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t sgi = 0; sgi < nseg; ++sgi) {
+            for (uint32_t i = 0; i < std::min<uint32_t>(counts[sgi], err_slots); ++i) mixed_errs.push_back(errs[sgi * err_slots + i]);
+        }
+        nerr += hdr.totals[1];
+    }
+    HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    hdr_dirty = false;
+    std::stable_sort(merged.begin(), merged.end(), [](const MsgDev &a, const MsgDev &b) { return a.capture < b.capture; });
+    if (merged.size() > msg_capacity) {
+        set_error("message list overflow: %zu messages, capacity %llu", merged.size(), (unsigned long long)msg_capacity);
+        return OOKD_ERR_CAPACITY;
+    }
+    if (!merged.empty()) memcpy(h_msgs, merged.data(), merged.size() * sizeof(MsgDev));
+    num_msgs = merged.size();
+    stats.num_messages = merged.size();
+    stats.num_errors = nerr;
+    stats.fsm_path = 3;                 // the scan, with the rounds for what it refused
+    stats.fsm_fallback_reason = reasons;
+    stats.fsm_iterations = rounds;
+    mixed_valid = true;
     return OOKD_OK;
 }
 
@@ -942,6 +1023,11 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.first = first;
     a.final_state = d_final_state.p;
     a.fallback = &d_hdr.p->scan_fallback;
+    if (run_caps > 1) {
+        HIPCHK(hipMemsetAsync(d_cap_fallback.p, 0, run_caps * sizeof(uint32_t), stream));
+        a.cap_fallback = d_cap_fallback.p;
+    }
+    a.edge_overflow = &d_hdr.p->edge_overflow;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = &d_hdr.p->fin_ticket;
@@ -1021,6 +1107,8 @@ int ookd_rx::enqueue_publish() {
 int ookd_rx::collect_results() {
     const uint64_t first = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
     uint32_t total_edges = 0;
+    bool redo_some = false;             // the scan left some captures of the batch to the rounds
+    mixed_valid = false;
     HIPCHK(hipStreamSynchronize(stream));
     hdr_dirty = false;              // the publish kernel left the device header zeroed
     if (scan_pending) {
@@ -1028,6 +1116,7 @@ int ookd_rx::collect_results() {
         if (h_hdr->scan_fallback == 0) {
             scan_used = true;
             stats.fsm_path = 1;
+            redo_some = run_caps > 1 && (h_hdr->flags & 2u) != 0;
         } else if (!chunks.empty()) {
             // the scan refused a chunk of a pipelined run: the whole capture again, unchunked (the
             // last chunk's publishing kernel left the device header zeroed)
@@ -1124,6 +1213,10 @@ int ookd_rx::collect_results() {
         num_msgs = total;
         stats.num_messages = total;
         stats.num_errors = h_hdr->totals[1];
+        if (redo_some) {
+            const int rc = redo_refused_captures();
+            if (rc != OOKD_OK) return rc;
+        }
         // (the scan's finish kernel numbers message slots capture-major, the round
         //  form's gather does too: the list is already in capture order)
     }
@@ -1401,6 +1494,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
+            rc |= rx->d_cap_fallback.alloc(caps);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
             rc |= rx->d_fin_off.alloc(caps + 1);
@@ -1800,6 +1894,11 @@ int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity, 
     if (num) *num = rx->stats.num_errors;
     if (!rx->have_fsm || rx->run_n_out == 0 || !samples || capacity == 0) return OOKD_OK;
     HIPCHK(hipSetDevice(rx->dev));
+    if (rx->mixed_valid) {              // scan + rounds for the captures it refused: the list lives on the host
+        const uint64_t n = std::min<uint64_t>(rx->mixed_errs.size(), capacity);
+        if (n) memcpy(samples, rx->mixed_errs.data(), n * 8);
+        return OOKD_OK;
+    }
     if (rx->scan_used) {
         const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(rx->stats.num_errors, capacity), rx->d_scan_errs.n);
         if (n) HIPCHK(hipMemcpy(samples, rx->d_scan_errs.p, n * 8, hipMemcpyDeviceToHost));

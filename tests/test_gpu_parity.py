@@ -594,6 +594,73 @@ def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle):
     rx.close()
 
 
+def test_batch_with_one_refused_capture_redoes_only_that_one(ok, oracle):
+    """A stretch of inert edges deeper than the scan's stuck codes hold (six short pulses inside ONE bit
+    gap of p3l-nexa2012: twelve edges on which nothing fires) makes the scan refuse that capture.  In a
+    batch the other captures keep the scan's results; the refused one is redone alone in the round form
+    and merged in, in capture order -- messages, payloads and error counts per capture as the oracle's."""
+    import torch
+    us = RATE // 1000000
+    sh = dict(bits=36, start=500, first=8700, pulse=500, gap0=2000, gap1=4000)
+
+    def message(bits, deep_at=None):
+        runs = [sh["start"] * us, sh["first"] * us]
+        for i, bit in enumerate(bits):
+            gap = (sh["gap1"] if bit else sh["gap0"]) * us
+            runs.append(sh["pulse"] * us)
+            if i == deep_at:
+                pre = []
+                for _ in range(6):
+                    pre += [150, 90]                    # low 150, glitch 90: ends long before any bit window opens
+                runs += pre + [gap - sum(pre)]
+            else:
+                runs.append(gap)
+        return runs + [sh["pulse"] * us, 20000]
+
+    rng = np.random.default_rng(9)
+    def capture(deep):
+        runs = [5000]
+        for m in range(6):
+            bits = rng.integers(0, 2, size=sh["bits"])
+            ones = [i for i, b in enumerate(bits) if b]
+            runs += message(bits, deep_at=(ones[len(ones) // 2] if (deep and m == 2 and ones) else None))
+        return _iq_from_stream(stream_from_runs(runs))
+
+    caps = [capture(False), capture(True), _iq_from_stream(stream_from_runs(_glitchy_message_runs("p3l-nexa2012", 5, seed=5))),
+            capture(False)]
+    n = max(c.size // 2 for c in caps)
+    stride = n + 8
+    host = np.zeros((len(caps), 2 * stride), dtype=np.int16)
+    for c, x in enumerate(caps):
+        host[c, :x.size] = x
+    dev_t = torch.from_numpy(host).cuda()
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    # alone, the deep capture leaves the scan (otherwise this test tests nothing)
+    solo = ok.Receiver(None, d, max_samples=n)
+    r1 = solo.rx(host[1, :2 * n])
+    assert r1.stats["fsm_path"] == 3 and r1.stats["fsm_fallback_reason"] != 0
+    solo.close()
+    rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
+    for order in ((0, 1, 2, 3), (0, 2, 3)):                 # with the refused capture, then a clean batch on the same context
+        sub = torch.from_numpy(host[list(order)].copy()).cuda()
+        got = rx.rx_device(sub.data_ptr(), n, num_captures=len(order), stride=stride)
+        assert got.stats["fsm_path"] == (3 if 1 in order else 1), got.stats
+        total = nerr = 0
+        for i, c in enumerate(order):
+            want = oracle.rx(host[c, :2 * n], None, 0.1, od, 8192)
+            gc = got.for_capture(i)
+            assert list(gc.msg_samples) == list(want.msg_samples), c
+            assert (gc.payloads == want.payloads).all(), c
+            total += len(want.msg_samples)
+            nerr += len(want.err_samples)
+        assert total == len(got.msg_samples) and total >= 15
+        assert got.stats["num_errors"] == nerr
+        errs, ne = rx.errors()
+        assert ne == nerr and len(errs) == nerr
+    rx.close()
+
+
 def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers):
     """One capture cut into shards (as 8 GPUs would hold it): halo + carried
     FSM state reproduce the single-pass result."""

@@ -190,12 +190,19 @@ def main():
         stats["cases"] += 1
         stats["messages"] += len(want.msg_samples)
         stats["errors"] += len(want.err_samples)
-        for fsm_rounds, scan_sims in ((False, False), (False, True), (True, False)):
+        # scan with span tables / with per-span simulation, rounds, and the scan pipelined in chunks of a few
+        # buffers (state carried on the device)
+        for fsm_rounds, scan_sims, chunk in ((False, False, 0), (False, True, 0), (True, False, 0),
+                                             (False, False, int(rng.choice([2, 4, 16])) * spb)):
             rx = ok.Receiver(f, d, max_samples=iq.size // 2, samples_per_buffer=spb, fsm_rounds=fsm_rounds,
-                             quiet_skip=not fsm_rounds, scan_sims=scan_sims)
+                             quiet_skip=not fsm_rounds, scan_sims=scan_sims, pipeline_chunk_samples=chunk)
             got = rx.rx(iq)
             stats["receivers"] += 1
-            if not fsm_rounds:
+            if chunk:
+                stats["pipelined"] = stats.get("pipelined", 0) + (1 if got.stats["pipeline_chunks"] else 0)
+                stats["pipelined_refused"] = stats.get("pipelined_refused", 0) + (
+                    1 if (not got.stats["pipeline_chunks"] and got.stats["fsm_fallback_reason"]) else 0)
+            elif not fsm_rounds:
                 stats["scan_runs"] += 1
                 if got.stats["fsm_path"] != 1:
                     stats["scan_refused"] += 1
@@ -207,7 +214,7 @@ def main():
                     and (nerr > 32 or list(errs) == list(want.err_samples)))
             if not good:
                 stats["mismatches"].append(dict(device=name, rate=rate, filter=fname, spb=spb, runs=[int(r) for r in runs],
-                                                fsm_rounds=fsm_rounds, scan_sims=scan_sims,
+                                                fsm_rounds=fsm_rounds, scan_sims=scan_sims, chunk=chunk,
                                                 want=[int(x) for x in want.msg_samples],
                                                 got=[int(x) for x in got.msg_samples]))
             rx.close()
