@@ -482,6 +482,10 @@ struct ScanParams {
     uint64_t pos_origin;        // the chunk's first decimated sample: added to message / error positions
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device), or null = 0
     const uint32_t *edge_overflow;      // the edge stage's overflow flag: the scan refuses such a run
+    // entry code of every leaf (scan_entry_kernel): the emit kernel then needs none of the tables
+    uint16_t *pre_codes;        // [edges + captures], or null: the emit kernel derives them per block
+    uint16_t *blk_in;           // [blocks] entry code of every block
+    uint32_t entry_phase;       // scan_entry_kernel: 0 groups -> blocks, 1 blocks -> chunks -> leaves
     uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
                                 // capture whose path leaves the model is left out of the results -- the host
                                 // redoes it alone in the round form -- instead of voiding the whole call
@@ -1359,6 +1363,88 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
     }
 }
 
+// The entry code of every leaf, exactly, from what leaf / groups / walk left behind -- in two small
+// lane-parallel passes instead of inside every emit workgroup (where thread 0 walked up to 15 block
+// tables and 4 chunk tables and 4 threads 16 leaves each, behind the staging of all those tables:
+// half of that kernel's time).
+//   phase 0: one lane per GROUP walks its <= 16 block tables from the group's entry state (scan_walk)
+//            -> entry code of every block;
+//   phase 1: one lane per CHUNK of 16 leaves: the block's entry code through the chunk tables in front
+//            of it, then the chunk's leaves through their packed rows -> entry code of every leaf.
+__global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ LTab T;
+    copy_ltab(T, sp.ltab);
+    __syncthreads();
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
+    __syncthreads();
+    if (*sp.fallback) return;
+    const uint32_t LB = sp.leaf_block;
+    if (sp.entry_phase == 0) {
+        const uint32_t ngroups = sp.cap_group_off[sp.f.num_captures];
+        for (uint32_t gg = blockIdx.x * blockDim.x + threadIdx.x; gg < ngroups; gg += gridDim.x * blockDim.x) {
+            uint32_t cap, lg;
+            locate_group(sp, gg, cap, lg);
+            const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
+            const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
+            uint32_t s = sp.group_in[gg];
+            for (uint32_t j = 0; j < nb; ++j) {
+                sp.blk_in[b0 + j] = (uint16_t)s;
+                s = sp.block_tab[(size_t)(b0 + j) * sp.Dp + s];
+            }
+        }
+        return;
+    }
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    const uint32_t cpb = LB / kChunk;                           // chunks per block
+    const uint32_t nsim = 2 * T.S + 2;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total * cpb; t += gridDim.x * blockDim.x) {
+        const uint32_t gb = t / cpb, c = t - gb * cpb;
+        uint32_t cap, lb;
+        locate_block(sp, gb, cap, lb);
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t first = 1 + (uint64_t)lb * LB;
+        const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+        if (c * kChunk >= count) continue;
+        const uint64_t *edges = sp.f.edges + e0;
+        const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
+        uint32_t s = sp.blk_in[gb];
+        const uint16_t *ctab = sp.chunk_tab + (size_t)gb * cpb * sp.Dp;
+        for (uint32_t j = 0; j < c; ++j) s = ctab[j * sp.Dp + s];
+        const uint32_t *res = sp.leaf_res + (e0 + cap + first) * nsim;
+        uint16_t *pre = sp.pre_codes + e0 + cap + first;
+        const uint32_t l1 = min((c + 1) * kChunk, count);
+        for (uint32_t l = c * kChunk; l < l1; ++l) {
+            pre[l] = (uint16_t)s;
+            // (leaf_step_packed wants the resume positions of the block's leaves: only a row that needs a
+            //  simulation reads it, so it is computed on the spot)
+            const uint32_t *row = res + (size_t)l * nsim;
+            const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
+            if (s >= SNB) {
+                if (s < SNB + 2) s = row[2 * S + (s - SNB)] & 0xffffu;
+                else if (s != SNB + 2) s = stuck_step(T, sc, first + l, s);
+                continue;
+            }
+            const uint32_t cur = s / NB1, nbits = s - cur * NB1;
+            const uint32_t pk = row[2 * cur + (nbits >= T.max_bits ? 1u : 0u)];
+            if (pk & kPkAbsolute) {
+                s = pk & 0xffffu;
+            } else if (pk & kPkRelative) {
+                const uint32_t nbo = nbits + ((pk >> 8) & 0xffffu);
+                s = (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+            } else if (pk & kPkStuck) {
+                s = stuck_enter(T, sc, s);
+            } else {
+                PSim f;                 // row depends on the exact bit count (rare): simulate
+                Acc a;
+                const bool alive = run_leaf(T, s, span_of(T, edges, first + l), next_buffer_start(T, edges[first + l - 1]), f, a);
+                s = encode_post(T, f, a, alive);
+            }
+        }
+    }
+}
+
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
 __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
@@ -1386,6 +1472,14 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             const uint64_t first = 1 + (uint64_t)lb * LB;
             const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
             const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
+            if (sp.pre_codes) {
+                // the leaves' entry codes are there already (scan_entry_kernel): no table is staged
+                for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+                    s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
+                    pre[l] = sp.pre_codes[e0 + cap + first + l];
+                }
+                __syncthreads();
+            } else {
             {
                 const uint32_t nsim = 2 * T.S + 2;
                 const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
@@ -1430,6 +1524,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 }
             }
             __syncthreads();
+            }   // no pre_codes
             // a wavefront takes the leaves entered in "its" states (state mod 16; skip
             // and poison codes form row S), so its lanes run the same triggers
             const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -2271,7 +2366,19 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     hipLaunchKernelGGL(scan_leaf_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
     hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
-    hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
+    if (a.pre_codes && a.blk_in) {
+        // entry codes of all leaves in two small passes; the emit kernel then stages no tables (and needs no LDS
+        // for them: more of its workgroups fit a CU)
+        sp.pre_codes = a.pre_codes;
+        sp.blk_in = a.blk_in;
+        sp.entry_phase = 0;
+        hipLaunchKernelGGL(scan_entry_kernel, dim3(64), dim3(256), 0, stream, sp);
+        sp.entry_phase = 1;
+        hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
+        hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), 0, stream, sp);
+    } else {
+        hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
+    }
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
     // t_end takes the last kernel's own end time stamp (no marker packet behind the chain)

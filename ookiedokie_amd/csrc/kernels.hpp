@@ -280,6 +280,8 @@ struct FsmScanArgs {
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device)
     const uint32_t *edge_overflow;      // the edge stage's overflow flag (device), or null
     uint32_t *cap_fallback;     // [captures] per-capture refusal bits (zero at launch), or null
+    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel), or null
+    uint16_t *blk_in;           // [total_blocks_cap] entry code of every block
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]

@@ -293,6 +293,7 @@ struct ookd_rx {
     bool no_pipeline_once = false;
     uint32_t front_launches = 1;    // of the last run
     DevBuf<uint32_t> d_cap_fallback;        // [captures] the scan's per-capture refusal bits (batched runs)
+    DevBuf<uint16_t> d_pre, d_blk_in;       // entry code of every leaf / block (scan_entry_kernel)
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
@@ -385,6 +386,8 @@ struct ookd_rx {
         d_quiet.release();
         d_carry.release();
         d_cap_fallback.release();
+        d_pre.release();
+        d_blk_in.release();
         d_chunk_totals.release();
         d_fin_tickets.release();
         for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
@@ -729,6 +732,8 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.pos_origin = ch.out0;
         a.totals_in = c ? d_chunk_totals.p + 2 * ((c - 1) & 1) : nullptr;
         a.edge_overflow = &d_hdr.p->edge_overflow;
+        a.pre_codes = d_pre.p;
+        a.blk_in = d_blk_in.p;
         a.final_state = d_carry.p + (c & 1);
         a.fallback = &d_hdr.p->scan_fallback;
         a.fin_off = d_fin_off.p;
@@ -1028,6 +1033,8 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
         a.cap_fallback = d_cap_fallback.p;
     }
     a.edge_overflow = &d_hdr.p->edge_overflow;
+    a.pre_codes = d_pre.p;
+    a.blk_in = d_blk_in.p;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = &d_hdr.p->fin_ticket;
@@ -1495,6 +1502,10 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
+            if (!getenv("OOKD_EMIT_TABLES")) {        // (the emit kernel deriving the entry codes itself: round 1's form)
+                rc |= rx->d_pre.alloc(rx->edge_capacity + caps + 8);
+                rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
+            }
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
             rc |= rx->d_fin_off.alloc(caps + 1);
