@@ -1067,7 +1067,8 @@ __device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const StuckC
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
 __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first, const uint32_t *cap,
                                const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
-                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach_base) {
+                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach_base, uint64_t *dbg = nullptr) {
+    STAMP(0);
     const uint32_t nch = (count + kChunk - 1) / kChunk;
     const uint32_t D0 = SNB + 3;
     // Only the codes a span can actually be entered in are walked (reach[], the
@@ -1078,54 +1079,65 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
     // (without a reach list every normal / skip entry is computed below; the stuck ones rarely)
     for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
     __syncthreads();
-    const uint32_t nitem = nch * NR;
-    // An item is a chain of up to 16 dependent LDS reads; a lane walks kIlp
-    // independent items side by side so that their latencies overlap.  A chain that
-    // gets stuck (rare) stops here and is finished below, out of the unrolled loop.
-    constexpr int kIlp = 5;
-    for (uint32_t base = threadIdx.x; base < nitem; base += blockDim.x * kIlp) {
-        uint32_t st[kIlp], l0[kIlp], l1[kIlp], dst[kIlp];
+    STAMP(1);
+    // A chain is up to 16 dependent LDS reads.  One wave takes one chunk (and a slab of
+    // 64 * kIlp codes) at a time: the leaf is then the same in every lane -- its row base and
+    // skip pair are fetched one step ahead, off the dependent path -- and a lane walks kIlp
+    // codes side by side, branch-free on the state (stuck codes wait like poison), so that one
+    // step costs one LDS latency.  (Round 2: the first form let the compiler put every chain
+    // step behind its own branch and wait, 10 latencies per step; 7.5 -> 1.5 us per block.)
+    // A chain that gets stuck (rare) stops here and is finished below, out of the hot loop.
+    constexpr int kIlp = 6;
+    const uint32_t lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: uniform loop bounds
+    const uint32_t slabs = (NR + 64u * kIlp - 1u) / (64u * kIlp);
+    const uint32_t *skipw = reinterpret_cast<const uint32_t *>(skip);     // [l]: skip[l][0] | skip[l][1] << 16
+    for (uint32_t unit = wave; unit < nch * slabs; unit += nwaves) {
+        const uint32_t c = unit / slabs, slab = unit - c * slabs;
+        const uint32_t l0 = c * kChunk, l1 = min(l0 + (uint32_t)kChunk, count);
+        const uint32_t lvl = (uint32_t)((first + l0) & 1ull) ^ T.lvl0;
+        uint32_t st[kIlp], code[kIlp], at[kIlp];      // at: leaf (relative to l0) in front of which the chain got stuck
+        bool valid[kIlp];
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
-            const uint32_t item = base + j * blockDim.x;
-            const uint32_t it = item < nitem ? item : 0u;
-            const uint32_t c = it / NR, idx = it - c * NR;
-            const uint32_t rv = reach ? (uint32_t)reach[idx] : (idx | 0xc000u);
-            st[j] = rv & 0x3fffu;
-            dst[j] = c * D + st[j];
-            l0[j] = c * kChunk;
-            l1[j] = item < nitem ? min((c + 1) * kChunk, count) : l0[j];
+            const uint32_t idx = slab * 64u * kIlp + (uint32_t)j * 64u + lane;
+            valid[j] = idx < NR;
+            const uint32_t rv = reach ? (uint32_t)reach[valid[j] ? idx : 0u] : (idx | 0xc000u);
+            code[j] = rv & 0x3fffu;
             // a code that is never met at the level of the chunk's first leaf stays poison
-            if (!((rv >> 14) & (1u << (((first + l0[j]) & 1ull) ^ T.lvl0)))) l1[j] = l0[j], st[j] = SNB + 2;
+            st[j] = (valid[j] && ((rv >> 14) & (1u << lvl))) ? code[j] : SNB + 2;
+            at[j] = kChunk;
         }
-        uint32_t at[kIlp];              // leaf (relative to l0) in front of which the chain got stuck
+        STAMP(2);
+        uint32_t rb = (uint32_t)rep[l0] * SNB, sk = skipw[l0];
+        for (uint32_t l = l0; l < l1; ++l) {
+            const uint32_t ln = l + 1 < l1 ? l + 1 : l;
+            const uint32_t repn = rep[ln], skn = skipw[ln];
+            uint32_t a[kIlp];
 #pragma unroll
-        for (int j = 0; j < kIlp; ++j) at[j] = kChunk;
-        for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
+            for (int j = 0; j < kIlp; ++j) a[j] = b.tab[rb + (st[j] < SNB ? st[j] : 0u)];
 #pragma unroll
             for (int j = 0; j < kIlp; ++j) {
-                const uint32_t l = l0[j] + step;
-                if (l < l1[j]) {
-                    // branch-free on the state (stuck codes wait like poison): the kIlp chains must stay interleaved
-                    const uint32_t v = st[j];
-                    const uint32_t a = b.tab[(uint32_t)rep[l] * SNB + (v < SNB ? v : 0u)];
-                    const uint32_t k = skip[l][v == SNB + 1 ? 1 : 0];
-                    const uint32_t nv = v < SNB ? a : (v < SNB + 2 ? k : v);
-                    at[j] = (nv > SNB + 2 && v <= SNB + 2) ? step + 1 : at[j];
-                    st[j] = nv;
-                }
+                const uint32_t v = st[j];
+                const uint32_t k = v == SNB + 1 ? sk >> 16 : sk & 0xffffu;
+                const uint32_t nv = v < SNB ? a[j] : (v < SNB + 2 ? k : v);
+                at[j] = (nv > SNB + 2 && v <= SNB + 2) ? l - l0 + 1 : at[j];
+                st[j] = nv;
             }
+            rb = repn * SNB;
+            sk = skn;
         }
+        STAMP(3);
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
-            const uint32_t item = base + j * blockDim.x;
-            if (item >= nitem) continue;
+            if (!valid[j]) continue;
             if (st[j] > SNB + 2) {
-                for (uint32_t l = l0[j] + at[j]; l < l1[j]; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
+                for (uint32_t l = l0 + at[j]; l < l1; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
             }
-            b.ctab[dst[j]] = (uint16_t)st[j];
+            b.ctab[c * D + code[j]] = (uint16_t)st[j];
         }
     }
+    STAMP(4);
     // chains that START in a stuck code: only behind a leaf that can end stuck -- nowhere in
     // a clean capture
     bool any = false;
@@ -1197,7 +1209,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t s_rep[256], s_uniq[258];
-    __shared__ uint16_t s_skip[256][2];
+    __shared__ __attribute__((aligned(4))) uint16_t s_skip[256][2];
     __shared__ uint32_t s_cap[kCapWords];
     __shared__ uint32_t s_lt[kLtLdsWords];
     copy_ltab(T, sp.ltab);
@@ -1260,7 +1272,8 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         }
         block_expand(T, sc, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach_base);
+        compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach_base,
+                       (sp.f.debug && gb == 2) ? sp.f.debug + 32 : nullptr);
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;

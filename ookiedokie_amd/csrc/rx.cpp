@@ -1052,6 +1052,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
         fprintf(stderr, "[scan] block_sims phases: resume %llu gap+rep %llu uniq %llu sims %llu\n",
                 (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
                 (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
+        fprintf(stderr, "[scan] compose phases: fill %llu setup %llu chains %llu finish %llu\n",
+                (unsigned long long)(dbg[33] - dbg[32]), (unsigned long long)(dbg[34] - dbg[33]),
+                (unsigned long long)(dbg[35] - dbg[34]), (unsigned long long)(dbg[36] - dbg[35]));
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans, cap %llx\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
@@ -1214,8 +1217,10 @@ int ookd_rx::collect_results() {
             return OOKD_ERR_CAPACITY;
         }
         if (total > first) {
-            HIPCHK(hipMemcpy(h_msgs + first, d_msgs.p + first, (total - first) * sizeof(MsgDev),
-                             hipMemcpyDeviceToHost));
+            // (on the context's stream, not the null stream: that one joins every blocking stream of the process)
+            HIPCHK(hipMemcpyAsync(h_msgs + first, d_msgs.p + first, (total - first) * sizeof(MsgDev),
+                                  hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
         }
         num_msgs = total;
         stats.num_messages = total;
