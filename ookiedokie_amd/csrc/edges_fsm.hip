@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
             const uint32_t tile_bits = (uint32_t)(kBlockWords * 64) / tpb;
             const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
             const uint32_t t0 = blk * tpb;
-            uint32_t prev_last = (t0 || p.has_prev) ? *(ti + t0 - 1) >> 31 : 0u;
+            uint32_t prev_last = (t0 || p.has_prev) ? tile_live(*(ti + t0 - 1), p.stamp_bits) >> 31 : 0u;
             uint32_t c = 0;
             // a block's tiles are 4, 8 or 16 consecutive words: fetch them 16 B at a time
             for (uint32_t t4 = 0; t4 < tpb; t4 += 4) {
@@ -101,15 +101,27 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
                 const uint32_t info4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; ++j) {
-                    // a tile that holds no sample was not written by the front end
+                    // a tile that holds no sample was not written by the front end; one without this
+                    // run's stamp is a quiet tile (sparse output)
                     const bool live = (uint64_t)(t0 + t4 + j) * tile_bits < p.n_out;
-                    const uint32_t info = live ? info4[j] : 0u;
-                    c += live ? (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+                    const uint32_t info = live ? tile_live(info4[j], p.stamp_bits) : 0u;
+                    c += live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
                     prev_last = live ? info >> 31 : prev_last;
                 }
             }
             v[i] = c;
-            p.blk_count[b] = c;         // edge_write skips empty blocks by it
+        }
+    }
+    // (one 16-byte store per lane where the lists allow it: four dword stores per lane are four
+    //  partial writes of every line)
+    const bool quad = base + 3 < n;
+    if (p.tile_info) {                  // edge_write skips empty blocks by the count
+        if (quad && ((uintptr_t)(p.blk_count + base) & 15u) == 0) {
+            *reinterpret_cast<uint4 *>(p.blk_count + base) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + i < n) p.blk_count[base + i] = v[i];
         }
     }
     const uint32_t mine = v[0] + v[1] + v[2] + v[3];
@@ -124,10 +136,15 @@ __global__ __launch_bounds__(256) void edge_scan_local_kernel(const EdgeParams p
     uint32_t before = 0;
     for (uint32_t w = 0; w < (tid >> 6); ++w) before += wave_sum[w];
     uint32_t run = before + inc - mine;
+    if (quad && ((uintptr_t)(p.blk_offset + base) & 15u) == 0) {
+        *reinterpret_cast<uint4 *>(p.blk_offset + base) = make_uint4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+        run += mine;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (base + i < n) p.blk_offset[base + i] = run;
-        run += v[i];
+        for (int i = 0; i < 4; ++i) {
+            if (base + i < n) p.blk_offset[base + i] = run;
+            run += v[i];
+        }
     }
     if (tid == 255) p.group_total[blockIdx.x] = run;
 }
@@ -231,12 +248,12 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
     const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     const uint32_t t0 = blk * tpb;
-    uint32_t prev_last = (t0 || p.has_prev) ? *(ti + t0 - 1) >> 31 : 0u;
+    uint32_t prev_last = (t0 || p.has_prev) ? tile_live(*(ti + t0 - 1), p.stamp_bits) >> 31 : 0u;
     uint64_t at = off;
     for (uint32_t t = 0; t < tpb; ++t) {
         const bool live = (uint64_t)(t0 + t) * tile_bits < p.n_out;
-        const uint32_t info = live ? ti[t0 + t] : 0u;
-        const uint32_t c = live ? (info & 0x3fffffffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+        const uint32_t info = live ? tile_live(ti[t0 + t], p.stamp_bits) : 0u;
+        const uint32_t c = live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
         if (c) {
             const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
             uint64_t carry = prev_last;
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(64) void fsm_prepare_kernel(const FsmParams p, cons
     } else {
         const uint64_t start = p.seg_bounds[(size_t)cap * (p.segs_per_cap + 1) + ls];
         if (start > 0 && start <= p.n_out) {
-            ss.st.prev = bit_at(p.bits + (uint64_t)cap * p.words_per_cap, start - 1);
+            ss.st.prev = fsm_level_at(p, cap, (int64_t)start - 1);
         }
         // assume the quiet state when the level before the segment is low
         if (ss.st.prev == 0) ss.st.cur = p.tables->quiet_state;

@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
     __shared__ uint32_t s_lt[kLtLdsWords];
     copy_ltab(T, sp.ltab);
     __syncthreads();
-    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     __shared__ LTab T;
     copy_ltab(T, sp.ltab);
     __syncthreads();
-    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t LB = sp.leaf_block;
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ uint16_t cin[32];
     copy_ltab(T, sp.ltab);
     __syncthreads();
-    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? (uint32_t)(sp.f.bits[-1] >> 63) : 0u;
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t D = T.D, LB = sp.leaf_block;
@@ -1642,7 +1642,7 @@ __device__ __forceinline__ void locate_fin(const ScanParams &sp, uint32_t gfb, u
 // workgroup inclusive scans over 1024 lanes: sums of (a, o, e) and max of r.
 // Shuffles inside each wavefront, one exchange of the 16 wave totals; the
 // inclusive values are also left in sh[k][lane] for the callers.
-__device__ void wg_scan4(uint32_t &a, uint32_t &o, uint32_t &e, uint32_t &r, uint32_t (*sh)[kFinBlock]) {
+__device__ __forceinline__ void wg_scan4(uint32_t &a, uint32_t &o, uint32_t &e, uint32_t &r, uint32_t (*sh)[kFinBlock]) {
     __shared__ uint32_t wtot[4][kFinBlock / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #pragma unroll
@@ -1688,7 +1688,7 @@ struct FinLeaf {                // one lane = one leaf of a finish block
     uint32_t a_tot, o_tot, e_tot, r_tot;
 };
 
-__device__ void fin_block_scan(const ScanParams &sp, uint32_t cap, uint32_t fb, FinLeaf &L,
+__device__ __forceinline__ void fin_block_scan(const ScanParams &sp, uint32_t cap, uint32_t fb, FinLeaf &L,
                                uint32_t (*sh)[kFinBlock]) {
     uint64_t e0;
     const uint64_t ne = cap_edges(sp.f, cap, e0);
@@ -1835,7 +1835,13 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             continue;
         }
         uint8_t *vals = sp.app_vals + pool0;
-        if (fb == 0 && tid < nb0) vals[tid] = (uint8_t)((fs.data[tid >> 6] >> (tid & 63)) & 1ull);
+        if (fb == 0 && tid < nb0) {
+            // (selects, not fs.data[tid >> 6]: a run-time index would put the state into scratch memory)
+            static_assert(kPayloadWords == 5, "select chain below");
+            const uint32_t q = tid >> 6;
+            const uint64_t w = q == 0 ? fs.data[0] : q == 1 ? fs.data[1] : q == 2 ? fs.data[2] : q == 3 ? fs.data[3] : fs.data[4];
+            vals[tid] = (uint8_t)((w >> (tid & 63)) & 1ull);
+        }
         if (fb == 0 && tid == 0 && nb0 > (uint32_t)kFinBlock) atomicOr(sp.fallback, (uint32_t)kFbPool);
         if (!L.have) continue;
         const uint32_t ai = a_before + L.a_in;
@@ -1852,18 +1858,23 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
             const uint64_t slot = base_e + e_before + L.e_in;
             if (slot < sp.err_capacity) sp.errs[slot] = L.ev.err_pos + sp.pos_origin;
         }
-        for (uint32_t j = 0; j < L.ev.nout && j < 2; ++j) {
-            const uint32_t ep = L.ev.out_rb[j] != 0xffu ? ai + L.ev.out_rb[j] : epoch;
-            const uint32_t have = ai + L.ev.out_ab[j] - ep;
+        // (constant indices: a run-time index into the record's arrays puts the whole record into
+        //  scratch memory -- 160 bytes per lane, written and read back: 118 MB per 16 GiB capture)
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            if (j >= L.ev.nout) break;
+            const uint32_t rb = j ? L.ev.out_rb[1] : L.ev.out_rb[0], ab = j ? L.ev.out_ab[1] : L.ev.out_ab[0];
+            const uint64_t opos = j ? L.ev.out_pos[1] : L.ev.out_pos[0];
+            const uint32_t ep = rb != 0xffu ? ai + rb : epoch;
+            const uint32_t have = ai + ab - ep;
             const uint64_t slot = base_m + o_before + L.o_in + j;
             if (slot < sp.f.msg_capacity) {
-                MsgDev mm;
-                mm.capture = cap;
-                mm.reserved = 0;
-                mm.sample = L.ev.out_pos[j] + sp.pos_origin;
-                mm.payload[0] = (uint64_t)ep | ((uint64_t)have << 32);     // resolved by fin_msg_kernel
-                mm.payload[1] = mm.payload[2] = mm.payload[3] = 0;
-                sp.f.msgs[slot] = mm;
+                uint4 *dst = reinterpret_cast<uint4 *>(sp.f.msgs + slot);
+                const uint64_t sample = opos + sp.pos_origin;
+                // capture, reserved | sample | payload[0] = epoch start | bits << 32 (resolved by fin_msg_kernel) | 0 ...
+                dst[0] = make_uint4(cap, 0u, (uint32_t)sample, (uint32_t)(sample >> 32));
+                dst[1] = make_uint4(ep, have, 0u, 0u);
+                dst[2] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         // outgoing state: the lane that owns the tail leaf

@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t fir1_tile_compute(const FrontParams &p, floa
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> (R - 1)) & 1u), 63);
-        info = cnt | (first << 30) | (last << 31);
+        info = cnt | (first << 30) | (last << 31) | p.stamp_bits;
     }
 
     // 64 / R lanes x R bits -> one 64-bit word
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(64 * kFirWgWaves) void fir1_bits_kernel(const Front
         const int L = p.quiet_lsb;
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
-            // sparse output: the tile's words and info are zero already (launch_clear_tiles; a check of the
-            // tile's old info in here instead -- 4 B per tile -- cost the kernel 10 %)
+            // sparse output: nothing is stored; whatever the tile's words and info hold carries an older
+            // run's stamp and reads as quiet (tile_live)
             if (!p.sparse) {
                 if (tid < kTile / 64) words[(t0 >> 6) + tid] = 0;
                 if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + t0 / kTile] = 0;
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nib & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((nib >> (G::R2 - 1)) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = cnt | (first << 30) | (last << 31);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = cnt | (first << 30) | (last << 31) | p.stamp_bits;
     }
     uint32_t half = nib << (4u * (tid & 7u));
     half |= __shfl_xor(half, 1);
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64) void nofir_bits_kernel(const FrontParams p) {
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> 15) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31);
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31) | p.stamp_bits;
     }
     const uint32_t pair = mask | (__shfl_xor(mask, 1) << 16);      // valid on even lanes
     const uint32_t hi = __shfl_xor(pair, 2);
@@ -1358,39 +1358,44 @@ hipError_t launch_front_stream(const FrontParams &p, StreamCtl ctl, bool exact, 
 }
 
 // ---------------------------------------------------------------------------
-// sparse front-end output: zero what the previous run wrote
+// sparse front-end output: making the bit words dense again
 // ---------------------------------------------------------------------------
 // With FrontParams::sparse the tuned 1-stage kernels store nothing for quiet
-// tiles; their words / infos must be zero when the run starts.  A tile whose
-// words are not all zero has a non-zero info (a level change inside it, or its
-// first bit set), so the previous run's infos tell which tiles to zero: one
-// pass over 4 B per tile (0.2 % of the capture's bytes).
+// tiles, and what an earlier run left there is told apart by the run stamp in
+// the tile info (tile_live): no pass over the tiles between runs (round 2 first
+// zeroed the previous run's tiles before every run: 60 us and 107 MB of
+// stores per 16 GiB capture, beside another context's front end).  This kernel
+// zeroes words + info of every tile that does not carry `keep_stamp_bits` (0:
+// every tile with a non-zero info): for readers of the raw words
+// (ookd_rx_get_bits), when the run geometry changes, when the stamp wraps.
 __global__ __launch_bounds__(256) void clear_tiles_kernel(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles,
                                                           uint32_t tiles_per_cap, uint64_t words_per_cap,
-                                                          uint32_t words_per_tile) {
+                                                          uint32_t words_per_tile, uint32_t keep_stamp_bits) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
     for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < ntiles; t += stride) {
         const uint4 q = *reinterpret_cast<const uint4 *>(tile_info + t);       // tiles_per_cap is a multiple of 8
         if ((q.x | q.y | q.z | q.w) == 0) continue;
-        const uint32_t info[4] = {q.x, q.y, q.z, q.w};
+        uint32_t info[4] = {q.x, q.y, q.z, q.w};
         for (uint32_t k = 0; k < 4; ++k) {
             if (!info[k]) continue;
+            if (keep_stamp_bits && !((info[k] ^ keep_stamp_bits) & kTileStampMask)) continue;      // this run's
             const uint64_t tt = t + k;
             const uint64_t cap = tt / tiles_per_cap, tile = tt - cap * tiles_per_cap;
             uint64_t *w = bits + cap * words_per_cap + tile * words_per_tile;
             for (uint32_t i = 0; i < words_per_tile; i += 2) *reinterpret_cast<uint4 *>(w + i) = make_uint4(0, 0, 0, 0);
+            info[k] = 0;
         }
-        *reinterpret_cast<uint4 *>(tile_info + t) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(tile_info + t) = make_uint4(info[0], info[1], info[2], info[3]);
     }
 }
 
 hipError_t launch_clear_tiles(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles, uint32_t tiles_per_cap,
-                              uint64_t words_per_cap, uint32_t tile_bits, hipStream_t stream) {
+                              uint64_t words_per_cap, uint32_t tile_bits, uint32_t keep_stamp_bits, hipStream_t stream) {
     if (ntiles == 0) return hipSuccess;
     uint64_t blocks = (ntiles / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(clear_tiles_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, tile_info, bits, ntiles,
-                       tiles_per_cap, words_per_cap, tile_bits / 64u);
+                       tiles_per_cap, words_per_cap, tile_bits / 64u, keep_stamp_bits);
     return hipGetLastError();
 }
 

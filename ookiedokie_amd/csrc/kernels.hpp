@@ -64,13 +64,28 @@ struct FrontParams {
                                 // | first bit << 30 | last bit << 31; [captures][tiles_per_cap]
     uint32_t tiles_per_cap;
     uint32_t tile_base;         // first wave tile of this launch (set by launch_front: chunked runs)
-    uint32_t sparse;            // tuned 1-stage kernels: quiet tiles store nothing (their words / infos are zero
-                                // already: launch_clear_tiles zeroed what the run before wrote)
+    uint32_t sparse;            // tuned 1-stage kernels: quiet tiles store nothing -- what an earlier run left in
+                                // their words / infos carries that run's stamp and reads as quiet (tile_live)
+    uint32_t stamp_bits;        // this run's stamp << kTileStampShift, OR-ed into every tile info written
 };
 
-// Sparse front-end output: zero the words / infos of the tiles the previous run wrote (non-zero info).
+// A tile info word:  level changes inside the tile (10 bits: tiles hold at most 1024 outputs)
+// | run stamp << 10 (20 bits) | first bit << 30 | last bit << 31.  Words and info of a tile are only
+// meaningful when the info carries the current run's stamp; anything else -- never written, or
+// left by an earlier run (sparse output) -- is a quiet tile: all bits zero.
+constexpr uint32_t kTileStampShift = 10;
+constexpr uint32_t kTileStampMask = 0x3ffffc00u;
+constexpr uint32_t kTileStampMax = 0xfffffu;
+// -> count | first << 30 | last << 31 of a live tile, 0 of a quiet / stale one
+__host__ __device__ __forceinline__ uint32_t tile_live(uint32_t info, uint32_t stamp_bits) {
+    return ((info ^ stamp_bits) & kTileStampMask) ? 0u : (info & ~kTileStampMask);
+}
+
+// Sparse front-end output: zero the words and infos of every tile whose info does not carry `keep_stamp_bits`
+// (0: of every tile with a non-zero info) -- makes the bit words dense again (ookd_rx_get_bits, a change of
+// the run geometry, the stamp wrapping around).  Not part of a normal run.
 hipError_t launch_clear_tiles(uint32_t *tile_info, uint64_t *bits, uint64_t ntiles, uint32_t tiles_per_cap,
-                              uint64_t words_per_cap, uint32_t tile_bits, hipStream_t stream);
+                              uint64_t words_per_cap, uint32_t tile_bits, uint32_t keep_stamp_bits, hipStream_t stream);
 // does this shape run on a kernel that honours FrontParams::sparse?
 bool front_sparse_capable(const FrontParams &p);
 
@@ -139,6 +154,7 @@ struct EdgeParams {
     uint32_t *total_acc;        // += the chunk's level changes, or null
     uint32_t has_prev;          // bits / tile_info continue in front of the chunk: the level before its first
                                 // sample is the last bit of the chunk before (0 for a capture's or shard's start)
+    uint32_t stamp_bits;        // the front end's (FrontParams::stamp_bits): tile infos without it are quiet tiles
 };
 
 hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);
@@ -211,7 +227,22 @@ struct FsmParams {
     uint64_t msg_capacity;
     uint64_t *totals;           // [0] messages, [1] errors
     uint64_t *debug;            // optional [segs][4]: loop turns, cycles, fused edges, window loads
+    // the bit words are only valid in tiles whose info carries the run's stamp (tile_live); null: everywhere
+    const uint32_t *tile_info;  // [captures][tiles_per_cap], offset like `bits` for a chunk
+    uint32_t tiles_per_cap;
+    uint32_t tile_shift;        // log2(outputs per tile)
+    uint32_t stamp_bits;
 };
+
+// level of decimated sample `pos` of capture `cap` (pos may be -1 for a chunk: the sample in front of it)
+__device__ __forceinline__ uint32_t fsm_level_at(const FsmParams &p, uint32_t cap, int64_t pos) {
+    if (p.tile_info) {
+        const int64_t tile = pos >> p.tile_shift;
+        if (!tile_live(p.tile_info[(int64_t)cap * p.tiles_per_cap + tile], p.stamp_bits)) return 0u;
+    }
+    const uint64_t *w = p.bits + (uint64_t)cap * p.words_per_cap;
+    return (uint32_t)((w[pos >> 6] >> (pos & 63)) & 1ull);
+}
 
 hipError_t launch_fsm_prepare(const FsmParams &p, const FsmStateDev *first_state,
                               hipStream_t stream);

@@ -273,10 +273,15 @@ struct ookd_rx {
     DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics)
     DevBuf<uint32_t> d_tile_info;   // per wave tile edge counts written by the tuned front-end kernels
     DevBuf<uint32_t> d_ctl;         // streaming front end: ticket heads | chunk counters | chunk ends
-    // sparse front-end output: extents of what the previous run may have written (zeroed by the next run)
+    // sparse front-end output: quiet tiles store nothing; the tile infos carry the run's stamp and tiles
+    // without it read as quiet (kernels.hpp: tile_live).  Extents of the previous run: a change of the
+    // geometry zeroes them first.
     bool sparse = false;
     uint64_t dirty_tiles = 0, dirty_words_per_cap = 0;
     uint32_t dirty_tiles_per_cap = 0;
+    uint32_t tile_stamp = 0;            // of the current run's front end, 1 .. kTileStampMax
+    mutable bool bits_dense = false;    // stale tiles of the current run were zeroed (ookd_rx_get_bits)
+    int densify_bits() const;
     // chunk pipeline (single-capture runs): front end on s_front, edges + state machine on s_chain, each
     // on its own half of the CUs
     bool pipe_ok = false;
@@ -475,6 +480,7 @@ struct ookd_rx {
             p.tiles_per_cap = tile_bits ? (uint32_t)(run_words * 64 / tile_bits) : 0;
         }
         p.sparse = sparse ? 1u : 0u;
+        p.stamp_bits = tile_stamp << kTileStampShift;
         return p;
     }
 
@@ -495,6 +501,7 @@ struct ookd_rx {
         if (tile_bits && d_tile_info.p) {
             e.tile_info = d_tile_info.p;
             e.tiles_per_block = (uint32_t)(kBlockWords * 64) / tile_bits;
+            e.stamp_bits = tile_stamp << kTileStampShift;
         }
         return e;
     }
@@ -528,6 +535,13 @@ struct ookd_rx {
         f.msg_capacity = msg_capacity;
         f.totals = d_hdr.p->totals;
         f.debug = d_debug.p;
+        const uint32_t tile_bits = front_tile_bits(front_params(nullptr, 0));
+        if (tile_bits && d_tile_info.p) {
+            f.tile_info = d_tile_info.p;
+            f.tiles_per_cap = (uint32_t)(run_words * 64 / tile_bits);
+            f.tile_shift = (uint32_t)__builtin_ctz(tile_bits);
+            f.stamp_bits = tile_stamp << kTileStampShift;
+        }
         return f;
     }
 
@@ -548,18 +562,47 @@ struct ookd_rx {
     bool submitted = false;         // a run is queued (ookd_rx_submit_device) and not yet waited for
 };
 
-// Sparse front-end output: quiet tiles store nothing, so zero what the run before wrote and
-// remember what this one may write (on the main stream, ahead of every front-end launch).
+// A new run of the front end: the next stamp.  Sparse output leaves the quiet tiles' words and infos
+// alone -- whatever they hold carries an older stamp and reads as quiet -- so nothing is zeroed between
+// runs, except when the geometry changes (rare; keeps "a zero info means zero words" simple to reason
+// about) or the 20-bit stamp wraps (every 2^20 - 1 runs): then every tile the buffer may hold is zeroed.
 int ookd_rx::prepare_front(FrontParams &fp) {
+    const uint32_t tile_bits = front_tile_bits(fp);
+    if (!tile_bits) return OOKD_OK;
     if (sparse) {
-        // quiet tiles store nothing: zero what the run before wrote (found by its non-zero tile infos),
-        // remember what this one may write
-        HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap,
-                                  front_tile_bits(fp), stream));
-        dirty_tiles = (uint64_t)run_caps * fp.tiles_per_cap;
+        const uint64_t tiles = (uint64_t)run_caps * fp.tiles_per_cap;
+        const bool same = tiles == dirty_tiles && fp.tiles_per_cap == dirty_tiles_per_cap && run_words == dirty_words_per_cap;
+        if (tile_stamp >= kTileStampMax) {
+            const uint64_t wpt = tile_bits / 64u;
+            const uint64_t all = std::min<uint64_t>(std::min<uint64_t>(d_tile_info.n, d_bits.n / wpt), 0xfffffff8ull) & ~(uint64_t)7;
+            // (the tile -> words mapping is linear: the whole buffer as one capture)
+            HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, all, (uint32_t)all, all * wpt, tile_bits, 0u, stream));
+            tile_stamp = 0;
+        } else if (!same && dirty_tiles) {
+            HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap,
+                                      tile_bits, 0u, stream));
+        }
+        dirty_tiles = tiles;
         dirty_tiles_per_cap = fp.tiles_per_cap;
         dirty_words_per_cap = run_words;
+    } else if (tile_stamp >= kTileStampMax) {
+        tile_stamp = 0;         // dense output rewrites every tile of a run
     }
+    ++tile_stamp;
+    bits_dense = !sparse;
+    fp.stamp_bits = tile_stamp << kTileStampShift;
+    return OOKD_OK;
+}
+
+// Readers of the raw bit words (ookd_rx_get_bits) want the quiet tiles zero: zero what earlier runs
+// left in the current run's extents.
+int ookd_rx::densify_bits() const {
+    if (bits_dense || !sparse || !dirty_tiles) return OOKD_OK;
+    const uint32_t tile_bits = front_tile_bits(front_params(nullptr, 0));
+    HIPCHK(launch_clear_tiles(d_tile_info.p, d_bits.p, dirty_tiles, dirty_tiles_per_cap, dirty_words_per_cap, tile_bits,
+                              tile_stamp << kTileStampShift, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    bits_dense = true;
     return OOKD_OK;
 }
 
@@ -677,11 +720,13 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         e.tiles_per_block = tiles_per_block;
         e.total_acc = &d_hdr.p->total_edges;
         e.has_prev = c ? 1u : 0u;
+        e.stamp_bits = fp.stamp_bits;
         HIPCHK(launch_edges(e, s_chain));
         // ---- its state machine, from the chunk before's outgoing state --------------------------------------
         FsmScanArgs a{};
         a.f = fsm_params();
         a.f.bits = e.bits;
+        a.f.tile_info = e.tile_info;
         a.f.words_per_cap = e.words_per_cap;
         a.f.edges = e.edges;
         a.f.blk_offset = e.blk_offset;
@@ -916,6 +961,7 @@ int ookd_rx::redo_refused_captures() {
         reasons |= flags[cap];
         FsmParams one = fsm_params();
         one.bits += (size_t)cap * run_words;
+        if (one.tile_info) one.tile_info += (size_t)cap * one.tiles_per_cap;
         one.blk_offset += (size_t)cap * run_blocks;     // (its entries are offsets into the one edge list)
         one.num_captures = 1;
         HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
@@ -1602,6 +1648,8 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         }
     }
     rx->gate = static_cast<ookd_rx_gate *>(cfg->front_gate);
+    // (tests: start the tile stamp near its wrap-around)
+    if (const char *e = getenv("OOKD_TILE_STAMP_START")) rx->tile_stamp = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 0), kTileStampMax);
     return rx.release();
 }
 
@@ -1848,6 +1896,10 @@ int ookd_rx_get_bits(const ookd_rx *rx, uint32_t capture, uint64_t *words, uint6
     if (!rx || !words || capture >= rx->run_caps) return OOKD_ERR_ARG;
     const uint64_t n = std::min<uint64_t>(capacity_words, rx->run_words);
     HIPCHK(hipSetDevice(rx->dev));
+    {
+        const int rc = rx->densify_bits();      // sparse front-end output: quiet tiles hold older runs' words
+        if (rc != OOKD_OK) return rc;
+    }
     HIPCHK(hipMemcpy(words, rx->d_bits.p + (size_t)capture * rx->run_words, n * 8, hipMemcpyDeviceToHost));
     return OOKD_OK;
 }
