@@ -483,7 +483,7 @@ struct ScanParams {
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device), or null = 0
     const uint32_t *edge_overflow;      // the edge stage's overflow flag: the scan refuses such a run
     // entry code of every leaf (scan_entry_kernel): the emit kernel then needs none of the tables
-    uint16_t *pre_codes;        // [edges + captures], or null: the emit kernel derives them per block
+    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [blocks] entry code of every block
     uint32_t entry_phase;       // scan_entry_kernel: 0 groups -> blocks, 1 blocks -> chunks -> leaves
     uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
@@ -498,8 +498,6 @@ struct ScanParams {
     uint32_t *fin_ticket;       // next finish block to hand out (zero at launch)
     uint32_t run_stamp;         // != 0, different from the previous launch's
     uint32_t fin_blocks_cap;
-    uint32_t *leaf_res;         // [edges + captures][2S+2] packed class-simulation results
-    uint16_t *chunk_tab;        // [blocks][leaf_block / 16][Dp] chunk tables of the leaf kernel, reused by emit
     // span tables (build_leaf_tables): packed result of a span as a function of its
     // length, per (row, level); null = simulate
     const uint32_t *lt_off, *lt_n0, *lt_pk;
@@ -1039,28 +1037,61 @@ static size_t block_lds_bytes(uint32_t LB, uint32_t D, uint32_t S, uint32_t SNB)
     return off;
 }
 
-// The same step from the packed class results alone (a few dozen steps per
-// block in the emit kernel: not worth a table).
-__device__ __forceinline__ uint32_t leaf_step_packed(const LTab &T, const StuckCtx &sc, const uint64_t *edges,
-                                                     uint64_t first, uint32_t l, const uint32_t *res,
-                                                     const uint64_t *resume, uint32_t s) {
+// One leaf applied to an abstract state code without any stored row: the span tables are searched
+// for the leaf's length (what block_sims does for the block's classes), position-dependent and
+// count-dependent cases are simulated.  i = the leaf (edge index in the capture), e_before / e_at =
+// edges[i - 1], edges[i].  Without span tables every step is a simulation.
+__device__ __noinline__ uint32_t leaf_step_fly(const LTab &T, const StuckCtx &sc, uint64_t i, uint64_t e_before,
+                                               uint64_t e_at, uint32_t s) {
     const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
-    const uint32_t *row = res + l * (2 * S + 2);
-    if (s >= SNB) {
-        if (s < SNB + 2) return row[2 * S + (s - SNB)] & 0xffffu;
-        return s == SNB + 2 ? s : stuck_step(T, sc, first + l, s);
+    if (s == SNB + 2) return s;                                 // poison stays
+    if (s > SNB + 2) return stuck_step(T, sc, i, s);
+    Span span;
+    span.pos0 = e_before + 1;
+    span.n = e_at - e_before - 1;
+    span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
+    span.has_edge = true;
+    span.prefix = 0;
+    uint64_t resume = 0;
+    if (sc.lt_off) {
+        if (s < SNB) {
+            if (span.n <= 0xfffffff0ull) {
+                const uint32_t cur = s / NB1, nb = s - cur * NB1;
+                const uint32_t p0 = lt_lookup(sc.lt_off, sc.lt_n0, sc.lt_pk, 2 * cur, span.L, (uint32_t)span.n);
+                uint32_t pk = p0 & ~kPkShared;
+                if (!(p0 & kPkShared) && nb >= T.max_bits) pk = lt_lookup(sc.lt_off, sc.lt_n0, sc.lt_pk, 2 * cur + 1, span.L, (uint32_t)span.n);
+                if (pk & kPkAbsolute) return pk & 0xffffu;
+                if (pk & kPkRelative) {
+                    const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+                    return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                }
+                if (pk & kPkStuck) return stuck_enter(T, sc, s);
+            }
+            resume = next_buffer_start(T, e_before);            // depends on the exact bit count, or a giant span
+        } else {
+            // a skip state: skipping ends at `resume`; from there the machine starts in reset -- the normal
+            // row (reset, no bits) of a shorter span when the level before the skip equals the span's, a
+            // special row otherwise (block_sims)
+            const uint32_t kk = s - SNB;
+            const uint64_t end_const = span.pos0 + span.n, last = end_const + 1;
+            resume = next_buffer_start(T, e_before);
+            if (resume >= last) return s;                        // still skipping when the span ends
+            const uint64_t n2 = resume >= end_const ? 0 : end_const - resume;
+            if (n2 <= 0xfffffff0ull) {
+                const uint32_t pk = lt_lookup(sc.lt_off, sc.lt_n0, sc.lt_pk, kk == span.L ? 0u : 2 * S + kk, span.L, (uint32_t)n2);
+                if (pk & kPkAbsolute) return pk & 0xffffu;
+                if (pk & kPkRelative) {
+                    const uint32_t nbo = (pk >> 8) & 0xffffu;   // from a bit count of 0
+                    return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                }
+            }
+        }
+    } else {
+        resume = next_buffer_start(T, e_before);
     }
-    const uint32_t cur = s / NB1, nb = s - cur * NB1;
-    const uint32_t pk = row[2 * cur + (nb >= T.max_bits ? 1u : 0u)];
-    if (pk & kPkAbsolute) return pk & 0xffffu;
-    if (pk & kPkRelative) {
-        const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
-        return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
-    }
-    if (pk & kPkStuck) return stuck_enter(T, sc, s);
-    PSim f;                     // row depends on the exact bit count (rare): simulate
+    PSim f;
     Acc a;
-    const bool alive = run_leaf(T, s, span_of(T, edges, first + l), resume[l], f, a);
+    const bool alive = run_leaf(T, s, span, resume, f, a);
     return encode_post(T, f, a, alive);
 }
 
@@ -1264,12 +1295,6 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         block_sims(T, edges, first, count, b.res, s_resume, s_rep, s_uniq, lt_off, lt_n0, lt_pk, s_cap,
                    (sp.f.debug && gb == 2) ? sp.f.debug + 40 : nullptr);
         const uint64_t st1 = __builtin_amdgcn_s_memtime();
-        {
-            // keep the packed results: the emit kernel rebuilds the tables from them
-            const uint32_t nsim = 2 * T.S + 2;
-            uint32_t *dst = sp.leaf_res + (e0 + cap + first) * nsim;
-            for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) dst[i] = b.res[i];
-        }
         block_expand(T, sc, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
         compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach_base,
@@ -1281,16 +1306,12 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             sp.f.debug[4 * gb + 2] = st3 - st2;
             sp.f.debug[4 * gb + 3] = s_uniq[0] | ((uint64_t)(s_cap[0] | s_cap[1] | s_cap[2]) << 32);
         }
-        // the block's table: every abstract state walks the chunk tables (kept for emit)
+        // the block's table: every abstract state walks the chunk tables -- all this kernel leaves behind
+        // (2 * Dp bytes per 64 leaves; the leaves' entry codes come from scan_entry_kernel)
         const uint32_t nch = (count + kChunk - 1) / kChunk;
-        uint16_t *ctab_out = sp.chunk_tab + (size_t)gb * (LB / kChunk) * sp.Dp;
         for (uint32_t d = threadIdx.x; d < D; d += blockDim.x) {
             uint32_t s = d;
-            for (uint32_t c = 0; c < nch; ++c) {
-                const uint32_t t = b.ctab[c * D + d];
-                ctab_out[c * sp.Dp + d] = (uint16_t)t;
-                s = c == 0 ? t : b.ctab[c * D + s];
-            }
+            for (uint32_t c = 0; c < nch; ++c) s = b.ctab[c * D + s];
             sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
         }
         __syncthreads();
@@ -1382,8 +1403,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
 // half of that kernel's time).
 //   phase 0: one lane per GROUP walks its <= 16 block tables from the group's entry state (scan_walk)
 //            -> entry code of every block;
-//   phase 1: one lane per CHUNK of 16 leaves: the block's entry code through the chunk tables in front
-//            of it, then the chunk's leaves through their packed rows -> entry code of every leaf.
+//   phase 1: one lane per BLOCK walks its leaves from the block's entry code, every step one search of
+//            the span tables (LDS) for the leaf's length -- the same packed row the leaf kernel built the
+//            block's tables from -> entry code of every leaf.  (First form: one lane per 16-leaf chunk
+//            from rows and chunk tables the leaf kernel stored for it -- 123 MB of stores per 16 GiB
+//            capture, and stores beside another context's front end cost it several times their share
+//            of the bandwidth: profiles/r02_interfere.txt.)
 __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ LTab T;
@@ -1408,52 +1433,41 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         }
         return;
     }
+    // the span tables (a few hundred words for the shipped devices) are searched from LDS
+    __shared__ uint32_t s_lt[kLtLdsWords];
+    const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
+    if (lt_off) {
+        const uint32_t noff = 2 * (2 * T.S + 2) + 1, nint = lt_off[noff - 1];
+        if (noff + 2 * nint <= kLtLdsWords) {
+            for (uint32_t i = threadIdx.x; i < noff; i += blockDim.x) s_lt[i] = sp.lt_off[i];
+            for (uint32_t i = threadIdx.x; i < nint; i += blockDim.x) {
+                s_lt[noff + i] = sp.lt_n0[i];
+                s_lt[noff + nint + i] = sp.lt_pk[i];
+            }
+            lt_off = s_lt;
+            lt_n0 = s_lt + noff;
+            lt_pk = s_lt + noff + nint;
+            __syncthreads();
+        }
+    }
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
-    const uint32_t cpb = LB / kChunk;                           // chunks per block
-    const uint32_t nsim = 2 * T.S + 2;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total * cpb; t += gridDim.x * blockDim.x) {
-        const uint32_t gb = t / cpb, c = t - gb * cpb;
+    for (uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x; gb < total; gb += gridDim.x * blockDim.x) {
         uint32_t cap, lb;
         locate_block(sp, gb, cap, lb);
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, cap, e0);
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
-        if (c * kChunk >= count) continue;
         const uint64_t *edges = sp.f.edges + e0;
-        const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
+        const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
         uint32_t s = sp.blk_in[gb];
-        const uint16_t *ctab = sp.chunk_tab + (size_t)gb * cpb * sp.Dp;
-        for (uint32_t j = 0; j < c; ++j) s = ctab[j * sp.Dp + s];
-        const uint32_t *res = sp.leaf_res + (e0 + cap + first) * nsim;
         uint16_t *pre = sp.pre_codes + e0 + cap + first;
-        const uint32_t l1 = min((c + 1) * kChunk, count);
-        for (uint32_t l = c * kChunk; l < l1; ++l) {
+        uint64_t before = edges[first - 1];
+        for (uint32_t l = 0; l < count; ++l) {
             pre[l] = (uint16_t)s;
-            // (leaf_step_packed wants the resume positions of the block's leaves: only a row that needs a
-            //  simulation reads it, so it is computed on the spot)
-            const uint32_t *row = res + (size_t)l * nsim;
-            const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
-            if (s >= SNB) {
-                if (s < SNB + 2) s = row[2 * S + (s - SNB)] & 0xffffu;
-                else if (s != SNB + 2) s = stuck_step(T, sc, first + l, s);
-                continue;
-            }
-            const uint32_t cur = s / NB1, nbits = s - cur * NB1;
-            const uint32_t pk = row[2 * cur + (nbits >= T.max_bits ? 1u : 0u)];
-            if (pk & kPkAbsolute) {
-                s = pk & 0xffffu;
-            } else if (pk & kPkRelative) {
-                const uint32_t nbo = nbits + ((pk >> 8) & 0xffffu);
-                s = (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
-            } else if (pk & kPkStuck) {
-                s = stuck_enter(T, sc, s);
-            } else {
-                PSim f;                 // row depends on the exact bit count (rare): simulate
-                Acc a;
-                const bool alive = run_leaf(T, s, span_of(T, edges, first + l), next_buffer_start(T, edges[first + l - 1]), f, a);
-                s = encode_post(T, f, a, alive);
-            }
+            const uint64_t at = edges[first + l];
+            s = leaf_step_fly(T, sc, first + l, before, at, s);
+            before = at;
         }
     }
 }
@@ -1464,14 +1478,12 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __shared__ LTab T;
     __shared__ uint64_t s_resume[256];
     __shared__ uint16_t pre[257];
-    __shared__ uint16_t cin[32];
     copy_ltab(T, sp.ltab);
     __syncthreads();
     if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
-    const uint32_t D = T.D, LB = sp.leaf_block;
-    const BlockLds b = carve(LB, D, T.S * T.NB1);
+    const uint32_t LB = sp.leaf_block;
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     // work items: every block, then one "ends" item per capture (first span + tail)
     for (uint32_t w = blockIdx.x; w < total + sp.f.num_captures; w += gridDim.x) {
@@ -1484,60 +1496,12 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             LeafEvDev *events = sp.events + e0 + cap;
             const uint64_t first = 1 + (uint64_t)lb * LB;
             const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
-            const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
-            if (sp.pre_codes) {
-                // the leaves' entry codes are there already (scan_entry_kernel): no table is staged
-                for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
-                    s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
-                    pre[l] = sp.pre_codes[e0 + cap + first + l];
-                }
-                __syncthreads();
-            } else {
-            {
-                const uint32_t nsim = 2 * T.S + 2;
-                const uint32_t *src = sp.leaf_res + (e0 + cap + first) * nsim;
-                for (uint32_t i = threadIdx.x; i < count * nsim; i += blockDim.x) b.res[i] = src[i];
-                for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
-                    s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
-                }
+            // the leaves' entry codes are there already (scan_entry_kernel): no table is staged
+            for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
+                s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
+                pre[l] = sp.pre_codes[e0 + cap + first + l];
             }
             __syncthreads();
-            const uint32_t nch = (count + kChunk - 1) / kChunk;
-            // blocks of this group that precede this one: their tables take the group's
-            // entry state (walk kernel) to this block's
-            const uint32_t jgrp = lb % kGroup;
-            {
-                // the leaf kernel's chunk tables of this block
-                const uint16_t *ctab_in = sp.chunk_tab + (size_t)w * (LB / kChunk) * sp.Dp;
-                for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) {
-                    const uint32_t c = i / D, d = i - c * D;
-                    b.ctab[i] = ctab_in[c * sp.Dp + d];
-                }
-                const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)(w - jgrp) * sp.Dp);
-                uint4 *dst = reinterpret_cast<uint4 *>(b.tab);          // the leaf-table area is free here
-                for (uint32_t i = threadIdx.x; i < jgrp * (sp.Dp / 8); i += blockDim.x) dst[i] = src[i];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {             // state entering the block, then each chunk
-                uint32_t s = sp.group_in[sp.cap_group_off[cap] + lb / kGroup];
-                for (uint32_t j = 0; j < jgrp; ++j) s = b.tab[j * sp.Dp + s];
-                for (uint32_t c = 0; c < nch; ++c) {
-                    cin[c] = (uint16_t)s;
-                    s = b.ctab[c * D + s];
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < nch) {            // state entering each leaf: walk the packed rows
-                const uint32_t c = threadIdx.x;
-                const uint32_t l1 = min((c + 1) * kChunk, count);
-                uint32_t s = cin[c];
-                for (uint32_t l = c * kChunk; l < l1; ++l) {
-                    pre[l] = (uint16_t)s;
-                    s = leaf_step_packed(T, sc, edges, first, l, b.res, s_resume, s);
-                }
-            }
-            __syncthreads();
-            }   // no pre_codes
             // a wavefront takes the leaves entered in "its" states (state mod 16; skip
             // and poison codes form row S), so its lanes run the same triggers
             const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -2328,8 +2292,6 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.fin_ticket = a.fin_ticket;
     sp.run_stamp = a.run_stamp;
     sp.fin_blocks_cap = a.fin_blocks_cap;
-    sp.leaf_res = a.leaf_res;
-    sp.chunk_tab = a.chunk_tab;
     sp.lt_off = a.lt_off;
     sp.lt_n0 = a.lt_n0;
     sp.lt_pk = a.lt_pk;
@@ -2354,8 +2316,6 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     hipError_t e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_leaf_kernel), lds);
     if (e != hipSuccess) return e;
-    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_emit_kernel), lds);
-    if (e != hipSuccess) return e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_walk_kernel), lds_walk);
     if (e != hipSuccess) return e;
     const uint32_t caps = a.f.num_captures;
@@ -2363,46 +2323,43 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     // leaf / emit are persistent grids: exactly as many workgroups as the chip holds at once (a
     // second, thinner round of the 1024 there used to be cost a third of their time)
     static thread_local int sim_dev = -1;
-    static thread_local uint32_t sim_grid = 0;
+    static thread_local uint32_t leaf_grid = 0, emit_grid = 0;
     static thread_local size_t sim_lds = 0;
     {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev != sim_dev || lds != sim_lds) {
-            int per_cu_leaf = 0, per_cu_emit = 0, cus = 0;
+            int per_cu_leaf = 0, per_cu_emit = 0;
             hipDeviceProp_t prop;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_leaf, scan_leaf_kernel, kSimThreads, lds) == hipSuccess &&
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_emit, scan_emit_kernel, kSimThreads, lds) == hipSuccess &&
-                hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-                cus = prop.multiProcessorCount;
-                const int per_cu = per_cu_leaf < per_cu_emit ? per_cu_leaf : per_cu_emit;
-                sim_grid = per_cu > 0 && cus > 0 ? (uint32_t)(per_cu * cus) : a.grid_blocks;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_emit, scan_emit_kernel, kSimThreads, 0) == hipSuccess &&
+                hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+                const int cus = prop.multiProcessorCount;
+                leaf_grid = per_cu_leaf > 0 ? (uint32_t)(per_cu_leaf * cus) : a.grid_blocks;
+                emit_grid = per_cu_emit > 0 ? (uint32_t)(per_cu_emit * cus) : a.grid_blocks;
             } else {
                 (void)hipGetLastError();
-                sim_grid = a.grid_blocks;
+                leaf_grid = emit_grid = a.grid_blocks;
             }
             sim_dev = dev;
             sim_lds = lds;
         }
     }
-    const uint32_t sim_blocks = getenv("OOKD_SCAN_GRID") ? (uint32_t)atoi(getenv("OOKD_SCAN_GRID")) : sim_grid;
+    static const char *const grid_env = getenv("OOKD_SCAN_GRID");
+    const uint32_t leaf_blocks = grid_env ? (uint32_t)atoi(grid_env) : leaf_grid;
+    const uint32_t emit_blocks = grid_env ? (uint32_t)atoi(grid_env) : emit_grid;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
-    hipLaunchKernelGGL(scan_leaf_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
+    hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
     hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
-    if (a.pre_codes && a.blk_in) {
-        // entry codes of all leaves in two small passes; the emit kernel then stages no tables (and needs no LDS
-        // for them: more of its workgroups fit a CU)
-        sp.pre_codes = a.pre_codes;
-        sp.blk_in = a.blk_in;
-        sp.entry_phase = 0;
-        hipLaunchKernelGGL(scan_entry_kernel, dim3(64), dim3(256), 0, stream, sp);
-        sp.entry_phase = 1;
-        hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
-        hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), 0, stream, sp);
-    } else {
-        hipLaunchKernelGGL(scan_emit_kernel, dim3(sim_blocks), dim3(kSimThreads), lds, stream, sp);
-    }
+    // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables
+    sp.pre_codes = a.pre_codes;
+    sp.blk_in = a.blk_in;
+    sp.entry_phase = 0;
+    hipLaunchKernelGGL(scan_entry_kernel, dim3(64), dim3(256), 0, stream, sp);
+    sp.entry_phase = 1;
+    hipLaunchKernelGGL(scan_entry_kernel, dim3(256), dim3(64), 0, stream, sp);
+    hipLaunchKernelGGL(scan_emit_kernel, dim3(emit_blocks), dim3(kSimThreads), 0, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);
     // t_end takes the last kernel's own end time stamp (no marker packet behind the chain)

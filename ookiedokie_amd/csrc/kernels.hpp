@@ -290,8 +290,6 @@ struct FsmScanArgs {
     uint32_t leaf_block;        // from fsm_scan_leaf_block()
     uint32_t grid_blocks;       // persistent workgroups for the leaf / emit kernels
     uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
-    uint32_t *leaf_res;         // [edges + captures][2S+2]
-    uint16_t *chunk_tab;        // [total_blocks_cap][leaf_block / 16][D rounded up to 8]
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
     PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
@@ -311,7 +309,7 @@ struct FsmScanArgs {
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device)
     const uint32_t *edge_overflow;      // the edge stage's overflow flag (device), or null
     uint32_t *cap_fallback;     // [captures] per-capture refusal bits (zero at launch), or null
-    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel), or null
+    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [total_blocks_cap] entry code of every block
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path

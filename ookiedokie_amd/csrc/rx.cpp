@@ -341,11 +341,11 @@ struct ookd_rx {
     uint32_t scan_reach_base = 0;   // reach entries below the stuck codes
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
-    DevBuf<uint16_t> d_block_tab, d_chunk_tab;
+    DevBuf<uint16_t> d_block_tab;
     DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
     DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
     DevBuf<uint16_t> d_reach;       // abstract codes a span can be entered in (empty = all)
-    DevBuf<uint32_t> d_leaf_res, d_cap_group_off;
+    DevBuf<uint32_t> d_cap_group_off;
     DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
@@ -416,13 +416,11 @@ struct ookd_rx {
         d_hdr.release();
         d_debug.release();
         d_block_tab.release();
-        d_chunk_tab.release();
         d_lt_off.release();
         d_lt_n0.release();
         d_lt_pk.release();
         d_ltab.release();
         d_reach.release();
-        d_leaf_res.release();
         d_cap_group_off.release();
         d_group_tab.release();
         d_group_in.release();
@@ -740,7 +738,6 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.leaf_block = scan_leaf_block;
         a.grid_blocks = 1024;
         a.block_tab = d_block_tab.p;
-        a.chunk_tab = d_chunk_tab.p;
         a.lt_off = d_lt_off.p;
         a.lt_n0 = d_lt_n0.p;
         a.lt_pk = d_lt_pk.p;
@@ -759,7 +756,6 @@ int ookd_rx::run_pipelined(const void *d_iq) {
             pp.first_msgs = std::min<uint64_t>(kHostMsgFirst, msg_capacity);
             a.publish = pp;
         }
-        a.leaf_res = d_leaf_res.p;
         a.cap_group_off = d_cap_group_off.p;
         a.group_tab = d_group_tab.p;
         a.group_in = d_group_in.p;
@@ -1049,7 +1045,6 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.leaf_block = scan_leaf_block;
     a.grid_blocks = 1024;
     a.block_tab = d_block_tab.p;
-    a.chunk_tab = d_chunk_tab.p;
     a.lt_off = d_lt_off.p;
     a.lt_n0 = d_lt_n0.p;
     a.lt_pk = d_lt_pk.p;
@@ -1058,7 +1053,6 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.nreach = (uint32_t)d_reach.n;
     a.nreach_base = scan_reach_base;
     a.publish = publish_params();
-    a.leaf_res = d_leaf_res.p;
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
     a.group_in = d_group_in.p;
@@ -1539,7 +1533,6 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rx->scan_leaf_block = fsm_scan_leaf_block(rx->scan_D, rx->scan_S, rx->scan_S * (rx->scan_max_bits + 2));
             rx->scan_blocks_cap = (uint32_t)(rx->edge_capacity / rx->scan_leaf_block + caps + 8);
             rc |= rx->d_block_tab.alloc((size_t)rx->scan_blocks_cap * ((rx->scan_D + 7u) & ~7u) + 64);
-            rc |= rx->d_chunk_tab.alloc((size_t)rx->scan_blocks_cap * (rx->scan_leaf_block / 16) * ((rx->scan_D + 7u) & ~7u) + 64);
             {
                 const size_t ngroups = rx->scan_blocks_cap / 16 + caps + 8;
                 rc |= rx->d_cap_group_off.alloc(caps + 1);
@@ -1547,16 +1540,13 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 rc |= rx->d_group_in.alloc(ngroups);
                 rc |= rx->d_cap_end.alloc(2 * (caps + 8));         // + cap_first
             }
-            rc |= rx->d_leaf_res.alloc((rx->edge_capacity + caps + 8) * (2 * (size_t)rx->scan_S + 2));
             rc |= rx->d_cap_block_off.alloc(caps + 1);
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
-            if (!getenv("OOKD_EMIT_TABLES")) {        // (the emit kernel deriving the entry codes itself: round 1's form)
-                rc |= rx->d_pre.alloc(rx->edge_capacity + caps + 8);
-                rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
-            }
+            rc |= rx->d_pre.alloc(rx->edge_capacity + caps + 8);
+            rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
             rc |= rx->d_fin_off.alloc(caps + 1);
