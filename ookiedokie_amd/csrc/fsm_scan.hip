@@ -82,6 +82,8 @@ struct LTab {
     uint32_t depth;                     // d = 1 .. depth <= kStuckDepth
     uint32_t lvl0;                      // level in front of the capture's first sample: 0, or (chunk of a pipelined run,
                                         // set by the kernels) the last bit of the chunk before; leaf i runs at lvl0 ^ (i & 1)
+    uint32_t buf_shift;                 // a buffer holds exactly 2^buf_shift decimated samples, or 0xffffffff: divide
+    uint32_t pad_[3];
     uint16_t stuck_src[kMaxStuck];      // ascending: the normal codes that can get stuck
     uint8_t stuck_row[kMaxStuckRows];   // row | level << 7: span-table rows with a stuck result, met at that level
 };
@@ -268,6 +270,8 @@ __host__ __device__ __forceinline__ uint32_t p_quiet(const LTab &T, const PSim &
 }
 
 __host__ __device__ __forceinline__ uint64_t next_buffer_start(const LTab &T, uint64_t pos) {
+    // spb = decim << buf_shift: buffer b holds the decimated samples [b << shift, (b + 1) << shift)
+    if (T.buf_shift != 0xffffffffu) return (pos | ((1ull << T.buf_shift) - 1ull)) + 1ull;
     const uint64_t in_idx = (uint64_t)T.decim * (pos + 1) - 1;
     const uint64_t buf = in_idx / T.spb;
     const uint64_t nb = ((buf + 1) * (uint64_t)T.spb) / T.decim;
@@ -483,7 +487,7 @@ struct ScanParams {
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device), or null = 0
     const uint32_t *edge_overflow;      // the edge stage's overflow flag: the scan refuses such a run
     // entry code of every leaf (scan_entry_kernel): the emit kernel then needs none of the tables
-    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel)
+    uint16_t *pre_codes;        // [blocks][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [blocks] entry code of every block
     uint32_t entry_phase;       // scan_entry_kernel: 0 groups -> blocks, 1 blocks -> chunks -> leaves
     uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
@@ -504,6 +508,7 @@ struct ScanParams {
     const void *ltab;           // device copy of the LTab (fsm_scan_fill_ltab)
     const uint16_t *reach;      // abstract codes a span can be entered in (from the span tables), or null = all
     uint32_t nreach, nreach_base;       // all of them / the normal, skip and poison codes among them (they come first)
+    uint32_t nreach_lv[2];              // reach + nreach: the base codes met at level 0, then those met at level 1
     uint32_t Dp, D;             // block table row pitch (D rounded up to 8); D = the domain with the stuck codes
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -1096,53 +1101,37 @@ __device__ __noinline__ uint32_t leaf_step_fly(const LTab &T, const StuckCtx &sc
 }
 
 // chunk tables: ctab[c][d] = the block's leaves 16c .. 16c+15 composed
-__device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first, const uint32_t *cap,
-                               const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
-                               const uint16_t (*skip)[2], const uint16_t *reach, uint32_t nreach_base, uint64_t *dbg = nullptr) {
-    STAMP(0);
-    const uint32_t nch = (count + kChunk - 1) / kChunk;
-    const uint32_t D0 = SNB + 3;
-    // Only the codes a span can actually be entered in are walked (reach[], the
-    // closure of the span tables' results; its first nreach_base entries are the
-    // normal / skip / poison codes); every other entry is poison, so a path that
-    // leaves the closure after all makes the capture fall back.
-    const uint32_t NR = reach ? nreach_base : D0;
-    // (without a reach list every normal / skip entry is computed below; the stuck ones rarely)
-    for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
-    __syncthreads();
-    STAMP(1);
-    // A chain is up to 16 dependent LDS reads.  One wave takes one chunk (and a slab of
-    // 64 * kIlp codes) at a time: the leaf is then the same in every lane -- its row base and
-    // skip pair are fetched one step ahead, off the dependent path -- and a lane walks kIlp
-    // codes side by side, branch-free on the state (stuck codes wait like poison), so that one
-    // step costs one LDS latency.  (Round 2: the first form let the compiler put every chain
-    // step behind its own branch and wait, 10 latencies per step; 7.5 -> 1.5 us per block.)
-    // A chain that gets stuck (rare) stops here and is finished below, out of the hot loop.
-    constexpr int kIlp = 6;
-    const uint32_t lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: uniform loop bounds
-    const uint32_t slabs = (NR + 64u * kIlp - 1u) / (64u * kIlp);
+//
+// Only the codes a span can actually be entered in are walked: reach_lv = the two plain lists
+// "normal / skip / poison codes met at level 0 / at level 1" (the closure of the span tables'
+// results, split by level on the host); every other entry is poison, so a path that leaves the
+// closure after all makes the capture fall back.  Without the lists every base code is walked.
+//
+// A chain is up to 16 dependent LDS reads.  One wave takes one chunk (and a slab of 64 * kIlp
+// codes) at a time: the leaf is then the same in every lane -- its row base and skip pair are
+// fetched one step ahead, off the dependent path -- and a lane walks kIlp codes side by side,
+// branch-free on the state (stuck codes wait like poison), so that one step costs one LDS
+// latency.  The kernel is bound by the LDS (random 2-byte reads, bank conflicts), so the reads
+// are what is saved: after the chunk's FIRST leaf the few hundred codes have collapsed to a
+// few dozen distinct states (the machine's states times the bit counts that survive), and
+// only those walk the other 15 leaves (`scratch`: a bit set per wave to find them; the chunk's
+// own ctab row holds their results until the codes have picked them up).
+// A chain that gets stuck (rare) stops and is finished out of the hot loop.
+constexpr int kComposeIlp = 7;
+
+// st[] through the leaves la .. lb-1 of the block (uniform bounds), kIlp chains per lane
+template <int kIlp>
+__device__ __forceinline__ void compose_walk(const LTab &T, const StuckCtx &sc, uint64_t first, const BlockLds &b, uint32_t SNB,
+                                             const uint16_t *rep, const uint16_t (*skip)[2], uint32_t la, uint32_t lb,
+                                             uint32_t (&st)[kIlp]) {
     const uint32_t *skipw = reinterpret_cast<const uint32_t *>(skip);     // [l]: skip[l][0] | skip[l][1] << 16
-    for (uint32_t unit = wave; unit < nch * slabs; unit += nwaves) {
-        const uint32_t c = unit / slabs, slab = unit - c * slabs;
-        const uint32_t l0 = c * kChunk, l1 = min(l0 + (uint32_t)kChunk, count);
-        const uint32_t lvl = (uint32_t)((first + l0) & 1ull) ^ T.lvl0;
-        uint32_t st[kIlp], code[kIlp], at[kIlp];      // at: leaf (relative to l0) in front of which the chain got stuck
-        bool valid[kIlp];
+    uint32_t at[kIlp];          // leaf in front of which the chain got stuck (lb: it did not)
 #pragma unroll
-        for (int j = 0; j < kIlp; ++j) {
-            const uint32_t idx = slab * 64u * kIlp + (uint32_t)j * 64u + lane;
-            valid[j] = idx < NR;
-            const uint32_t rv = reach ? (uint32_t)reach[valid[j] ? idx : 0u] : (idx | 0xc000u);
-            code[j] = rv & 0x3fffu;
-            // a code that is never met at the level of the chunk's first leaf stays poison
-            st[j] = (valid[j] && ((rv >> 14) & (1u << lvl))) ? code[j] : SNB + 2;
-            at[j] = kChunk;
-        }
-        STAMP(2);
-        uint32_t rb = (uint32_t)rep[l0] * SNB, sk = skipw[l0];
-        for (uint32_t l = l0; l < l1; ++l) {
-            const uint32_t ln = l + 1 < l1 ? l + 1 : l;
+    for (int j = 0; j < kIlp; ++j) at[j] = lb;
+    if (la < lb) {
+        uint32_t rb = (uint32_t)rep[la] * SNB, sk = skipw[la];
+        for (uint32_t l = la; l < lb; ++l) {
+            const uint32_t ln = l + 1 < lb ? l + 1 : l;
             const uint32_t repn = rep[ln], skn = skipw[ln];
             uint32_t a[kIlp];
 #pragma unroll
@@ -1152,21 +1141,132 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
                 const uint32_t v = st[j];
                 const uint32_t k = v == SNB + 1 ? sk >> 16 : sk & 0xffffu;
                 const uint32_t nv = v < SNB ? a[j] : (v < SNB + 2 ? k : v);
-                at[j] = (nv > SNB + 2 && v <= SNB + 2) ? l - l0 + 1 : at[j];
+                at[j] = (nv > SNB + 2 && v <= SNB + 2) ? l + 1 : at[j];
                 st[j] = nv;
             }
             rb = repn * SNB;
             sk = skn;
         }
-        STAMP(3);
+    }
+#pragma unroll
+    for (int j = 0; j < kIlp; ++j) {
+        if (st[j] > SNB + 2) {
+            for (uint32_t l = at[j]; l < lb; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+    // the LDS executes one wave's accesses in order: only keep the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first, const uint32_t *cap,
+                               const BlockLds &b, uint32_t D, uint32_t SNB, uint32_t count, const uint16_t *rep,
+                               const uint16_t (*skip)[2], const uint16_t *reach_lv, uint32_t nreach_lv,
+                               uint32_t *scratch, uint32_t scratch_words, uint64_t *dbg = nullptr) {
+    STAMP(0);
+    constexpr int kIlp = kComposeIlp;
+    const uint32_t nch = (count + kChunk - 1) / kChunk;
+    const uint32_t D0 = SNB + 3;
+    const uint32_t NR = reach_lv ? nreach_lv : D0;
+    for (uint32_t i = threadIdx.x; i < nch * D; i += blockDim.x) b.ctab[i] = (uint16_t)(SNB + 2);
+    __syncthreads();
+    STAMP(1);
+    const uint32_t lane = threadIdx.x & 63u, nwaves = blockDim.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: uniform loop bounds
+    const uint32_t slabs = (NR + 64u * kIlp - 1u) / (64u * kIlp);
+    // distinct states after the first leaf: a bit set of the base codes + their list, per wave
+    const uint32_t set_words = (D0 + 31u) / 32u;
+    const uint32_t per_wave = set_words + (64u * kIlp + 1u) / 2u;
+    const bool dedupe = slabs == 1 && set_words <= 64u && per_wave * nwaves <= scratch_words;
+    uint32_t *seen = scratch + wave * per_wave;
+    if (dbg && threadIdx.x == 0) dbg[8] = (dedupe ? 1u : 0u) | (slabs << 4) | ((uint64_t)NR << 16) | ((uint64_t)scratch_words << 32) | ((uint64_t)per_wave << 48);
+    uint16_t *list = reinterpret_cast<uint16_t *>(seen + set_words);
+    for (uint32_t unit = wave; unit < nch * slabs; unit += nwaves) {
+        const uint32_t c = unit / slabs, slab = unit - c * slabs;
+        const uint32_t l0 = c * kChunk, l1 = min(l0 + (uint32_t)kChunk, count);
+        uint32_t st[kIlp], code[kIlp];
+        bool valid[kIlp];
 #pragma unroll
         for (int j = 0; j < kIlp; ++j) {
-            if (!valid[j]) continue;
-            if (st[j] > SNB + 2) {
-                for (uint32_t l = l0 + at[j]; l < l1; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
-            }
-            b.ctab[c * D + code[j]] = (uint16_t)st[j];
+            const uint32_t idx = slab * 64u * kIlp + (uint32_t)j * 64u + lane;
+            valid[j] = idx < NR;
+            code[j] = reach_lv ? (uint32_t)reach_lv[valid[j] ? idx : 0u] : idx;
+            st[j] = valid[j] ? code[j] : SNB + 2;
         }
+        STAMP(2);
+        uint16_t *row = b.ctab + c * D;
+        if (!dedupe || l1 - l0 < 3) {
+            compose_walk<kIlp>(T, sc, first, b, SNB, rep, skip, l0, l1, st);
+        } else {
+            compose_walk<kIlp>(T, sc, first, b, SNB, rep, skip, l0, l0 + 1, st);
+            STAMP(5);
+            // ---- the distinct base codes among st[] ---------------------------------------------
+            if (lane < set_words) seen[lane] = 0;
+            wave_sync_lds();
+#pragma unroll
+            for (int j = 0; j < kIlp; ++j)
+                if (valid[j] && st[j] < D0) atomicOr(&seen[st[j] >> 5], 1u << (st[j] & 31u));
+            wave_sync_lds();
+            uint32_t bits = lane < set_words ? seen[lane] : 0u;
+            const uint32_t cnt = (uint32_t)__popc(bits);
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d);
+                if ((int)lane >= d) inc += t;
+            }
+            const uint32_t nd = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            uint32_t at = inc - cnt;
+            while (bits) {
+                const uint32_t bit = (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                list[at++] = (uint16_t)(lane * 32u + bit);
+            }
+            wave_sync_lds();
+            STAMP(6);
+            if (dbg && threadIdx.x == 0) dbg[9] = nd | ((uint64_t)NR << 32);
+            // ---- they walk the rest of the chunk; results parked in the chunk's own row -----------
+            for (uint32_t base = 0; base < nd; base += 64u * kIlp) {
+                uint32_t ds[kIlp], dv[kIlp];
+#pragma unroll
+                for (int j = 0; j < kIlp; ++j) {
+                    const uint32_t i = base + (uint32_t)j * 64u + lane;
+                    dv[j] = i < nd ? (uint32_t)list[i] : SNB + 2;
+                    ds[j] = dv[j];
+                }
+                compose_walk<kIlp>(T, sc, first, b, SNB, rep, skip, l0 + 1, l1, ds);
+#pragma unroll
+                for (int j = 0; j < kIlp; ++j)
+                    if (base + (uint32_t)j * 64u + lane < nd) row[dv[j]] = (uint16_t)ds[j];
+            }
+            wave_sync_lds();
+            STAMP(7);
+            // ---- every code picks up the result of the state its first leaf led to ------------------
+            uint32_t stuck1 = 0;
+#pragma unroll
+            for (int j = 0; j < kIlp; ++j) {
+                if (st[j] < D0) st[j] = row[st[j]];
+                else stuck1 |= 1u << j;         // got stuck on the first leaf (rare): finished below
+            }
+            wave_sync_lds();
+            for (uint32_t i = lane; i < nd; i += 64) row[list[i]] = (uint16_t)(SNB + 2);
+            wave_sync_lds();
+            if (stuck1) {
+#pragma unroll
+                for (int j = 0; j < kIlp; ++j) {
+                    if (!((stuck1 >> j) & 1u)) continue;
+                    for (uint32_t l = l0 + 1; l < l1; ++l) st[j] = leaf_step(T, sc, first, b.tab, rep, skip, SNB, l, st[j]);
+                }
+            }
+        }
+        STAMP(3);
+#pragma unroll
+        for (int j = 0; j < kIlp; ++j)
+            if (valid[j]) row[code[j]] = (uint16_t)st[j];
     }
     STAMP(4);
     // chains that START in a stuck code: only behind a leaf that can end stuck -- nowhere in
@@ -1297,8 +1397,14 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
         const uint64_t st1 = __builtin_amdgcn_s_memtime();
         block_expand(T, sc, edges, first, count, b.tab, b.res, s_resume, s_rep, s_skip);
         const uint64_t st2 = __builtin_amdgcn_s_memtime();
-        compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, sp.reach, sp.nreach_base,
-                       (sp.f.debug && gb == 2) ? sp.f.debug + 32 : nullptr);
+        {
+            // (a chunk starts on a multiple of 16 leaves: all chunks of the block start at the block's level)
+            const uint32_t lvl = (uint32_t)(first & 1ull) ^ T.lvl0;
+            const uint16_t *lv = sp.reach ? sp.reach + sp.nreach + (lvl ? sp.nreach_lv[0] : 0u) : nullptr;
+            // the packed rows are dead once the leaf tables are expanded: their LDS is the composition's scratch
+            compose_chunks(T, sc, first, s_cap, b, D, T.S * T.NB1, count, s_rep, s_skip, lv, sp.reach ? sp.nreach_lv[lvl] : 0u,
+                           b.res, LB * (2 * T.S + 2), (sp.f.debug && gb == 2) ? sp.f.debug + 48 : nullptr);
+        }
         const uint64_t st3 = __builtin_amdgcn_s_memtime();
         if (sp.f.debug && threadIdx.x == 0 && gb < 8) {
             sp.f.debug[4 * gb + 0] = st1 - st0;
@@ -1315,6 +1421,308 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
             sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// leaf kernel, table-driven form: ONE WAVE per block of 64 leaves
+// ---------------------------------------------------------------------------
+// scan_leaf_kernel above gives a block to a workgroup of four waves, and most of a block's
+// steps are narrow (64 leaves = one wave's worth; the other three wait at barriers) and long
+// chains of dependent, cheap instructions: it is bound by instruction issue and latency on the
+// one busy wave, with the expanded leaf tables (2 * S * NB1 bytes per leaf) limiting a CU to
+// two or three blocks at a time.  With span tables a row of a leaf is one table search, so here
+// lane l simply owns leaf l: its 2S+2 packed rows straight from the span tables (no search for
+// equal spans, no expanded tables), and the chunk composition evaluates the packed rows
+// directly (a multiply-high for state / bit count, one LDS read, a few selects per step).  LDS
+// per block: the packed rows + four chunk tables (~6 KB for the shipped devices), no workgroup
+// barrier anywhere, a dozen blocks per CU at a time.  The block tables are the same bit for bit.
+
+struct WaveLds {
+    uint32_t *res;      // [64][2S+2]
+    uint16_t *ctab;     // [64 / kChunk][D]
+};
+__host__ __device__ __forceinline__ size_t wave_lds_bytes(uint32_t D, uint32_t S) {
+    return (size_t)64 * (2 * S + 2) * 4 + ((size_t)(64 / kChunk) * D * 2 + 15) / 16 * 16;
+}
+
+// one step of the slow path: everything leaf_step_fly knows, from the block's packed rows
+__device__ __noinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
+                                                uint32_t l, const uint32_t *res, const uint64_t *resume, uint32_t s) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
+    const uint32_t *row = res + l * (2 * S + 2);
+    if (s >= SNB) {
+        if (s < SNB + 2) return row[2 * S + (s - SNB)] & 0xffffu;
+        return s == SNB + 2 ? s : stuck_step(T, sc, first + l, s);
+    }
+    const uint32_t cur = s / NB1, nb = s - cur * NB1;
+    const uint32_t pk = row[2 * cur + (nb >= T.max_bits ? 1u : 0u)];
+    if (pk & kPkAbsolute) return pk & 0xffffu;
+    if (pk & kPkRelative) {
+        const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+        return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+    }
+    if (pk & kPkStuck) return stuck_enter(T, sc, s);
+    PSim f;                     // row depends on the exact bit count (rare): simulate
+    Acc a;
+    const bool alive = run_leaf(T, s, span_of(T, edges, first + l), resume[l], f, a);
+    return encode_post(T, f, a, alive);
+}
+
+// K chains per lane, each through the leaves la[j] .. lb[j]-1 of the block
+template <int K>
+__device__ __forceinline__ void wave_walk(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
+                                          const uint32_t *res, const uint64_t *resume, uint32_t nsim, uint32_t rcpNB1,
+                                          const uint32_t (&la)[K], const uint32_t (&lb)[K], uint32_t (&st)[K]) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, max_bits = T.max_bits;
+    uint32_t stop[K];           // leaf at which the chain left the fast path (lb: it did not)
+#pragma unroll
+    for (int j = 0; j < K; ++j) stop[j] = lb[j];
+    for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
+        uint32_t pk[K], nb[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t v = st[j], l = la[j] + step;
+            const uint32_t cur = __umulhi(v, rcpNB1);           // v / NB1 (exact below 2^16)
+            nb[j] = v - cur * NB1;
+            const uint32_t col = v < SNB ? 2u * cur + (nb[j] >= max_bits ? 1u : 0u) : 2u * S + (v == SNB + 1 ? 1u : 0u);
+            pk[j] = res[(l < lb[j] ? l : la[j]) * nsim + col];
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t v = st[j], l = la[j] + step;
+            const uint32_t nbo = nb[j] + ((pk[j] >> 8) & 0xffffu);
+            const uint32_t rel = (pk[j] & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+            const uint32_t fast = (pk[j] & kPkAbsolute) ? (pk[j] & 0xffffu) : rel;
+            const bool live = l < lb[j] && stop[j] == lb[j] && v < SNB + 2;      // poison (SNB + 2) stays
+            const bool ok = (pk[j] & (kPkAbsolute | kPkRelative)) != 0;
+            st[j] = (live && ok) ? fast : v;
+            stop[j] = (live && !ok) ? l : stop[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        for (uint32_t l = stop[j]; l < lb[j]; ++l) st[j] = wave_step_slow(T, sc, edges, first, l, res, resume, st[j]);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
+                                             const WaveLds &b, const uint64_t *resume, uint32_t D, uint32_t count,
+                                             const uint16_t *reach_lv, uint32_t NR, uint32_t rcpNB1, uint32_t base) {
+    const uint32_t SNB = T.S * T.NB1, nsim = 2 * T.S + 2;
+    const uint32_t nch = (count + kChunk - 1) / kChunk, nitem = nch * NR;
+    const uint32_t lane = threadIdx.x;
+    uint32_t la[K], lb[K], st[K], dst[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const uint32_t item = base + (uint32_t)j * 64u + lane;
+        const bool valid = item < nitem;
+        const uint32_t it = valid ? item : 0u;
+        const uint32_t c = it / NR, idx = it - c * NR;
+        const uint32_t code = reach_lv ? (uint32_t)reach_lv[idx] : idx;
+        la[j] = c * kChunk;
+        lb[j] = valid ? min((c + 1) * (uint32_t)kChunk, count) : la[j];
+        st[j] = code;
+        dst[j] = valid ? c * D + code : 0xffffffffu;
+    }
+    wave_walk<K>(T, sc, edges, first, b.res, resume, nsim, rcpNB1, la, lb, st);
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (dst[j] != 0xffffffffu) b.ctab[dst[j]] = (uint16_t)st[j];
+    (void)SNB;
+}
+
+__global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ LTab T;
+    __shared__ uint64_t s_resume[64];
+    __shared__ uint32_t s_cap[kCapWords];
+    __shared__ uint32_t s_lt[kLtLdsWords];
+    copy_ltab(T, sp.ltab);
+    wave_sync_lds();
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
+    wave_sync_lds();
+    if (*sp.fallback) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D, nsim = 2 * S + 2, max_bits = T.max_bits;
+    const uint32_t D0 = SNB + 3;
+    const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + NB1 - 1) / NB1);
+    WaveLds b;
+    b.res = reinterpret_cast<uint32_t *>(scan_smem);
+    b.ctab = reinterpret_cast<uint16_t *>(scan_smem + (size_t)64 * nsim * 4);
+    // the span tables are searched from LDS when they fit (the shipped devices: 409 words)
+    const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
+    {
+        const uint32_t noff = 2 * nsim + 1, nint = lt_off[noff - 1];
+        if (noff + 2 * nint <= kLtLdsWords) {
+            for (uint32_t i = lane; i < noff; i += 64) s_lt[i] = sp.lt_off[i];
+            for (uint32_t i = lane; i < nint; i += 64) {
+                s_lt[noff + i] = sp.lt_n0[i];
+                s_lt[noff + nint + i] = sp.lt_pk[i];
+            }
+            lt_off = s_lt;
+            lt_n0 = s_lt + noff;
+            lt_pk = s_lt + noff + nint;
+            wave_sync_lds();
+        }
+    }
+    const uint32_t LB = sp.leaf_block;          // 64
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    for (uint32_t gb = blockIdx.x; gb < total + sp.f.num_captures; gb += gridDim.x) {
+        if (gb >= total) {
+            // one extra item per capture: its first span from the concrete incoming state (for the walk kernel)
+            if (lane == 0) {
+                const uint32_t cap = gb - total;
+                uint64_t e0;
+                const uint64_t ne = cap_edges(sp.f, cap, e0);
+                PSim f;
+                Acc a;
+                const bool alive = first_leaf(T, sp, sp.f.edges + e0, ne, f, a);
+                sp.cap_first[cap] = (uint16_t)encode_post(T, f, a, alive);
+            }
+            continue;
+        }
+        uint32_t cap, lb;
+        locate_block(sp, gb, cap, lb);
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t *edges = sp.f.edges + e0;
+        const uint64_t first = 1 + (uint64_t)lb * LB;
+        const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+        const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
+        const uint32_t nch = (count + kChunk - 1) / kChunk;
+        // ---- lane l = leaf l: its packed rows --------------------------------------------------
+        if (lane < kCapWords) s_cap[lane] = 0;
+        for (uint32_t i = lane; i < nch * D; i += 64) b.ctab[i] = (uint16_t)(SNB + 2);
+        if (lane < count) {
+            const uint32_t l = lane;
+            const Span span = span_of(T, edges, first + l);
+            const uint64_t rs = next_buffer_start(T, span.pos0 - 1);
+            s_resume[l] = rs;
+            uint32_t *row = b.res + l * nsim;
+            if (span.n <= 0xfffffff0ull) {
+                const uint32_t n = (uint32_t)span.n;
+                for (uint32_t k = 0; k < S; ++k) {
+                    const uint32_t p0 = lt_lookup(lt_off, lt_n0, lt_pk, 2 * k, span.L, n);
+                    const uint32_t p1 = (p0 & kPkShared) ? p0 : lt_lookup(lt_off, lt_n0, lt_pk, 2 * k + 1, span.L, n);
+                    row[2 * k] = p0 & ~kPkShared;
+                    row[2 * k + 1] = p1 & ~kPkShared;
+                }
+            } else {
+                // too long for the tables' 32-bit lengths: simulate both classes of every state
+                for (uint32_t k = 0; k < S; ++k) {
+                    PSim f;
+                    Acc a;
+                    bool alive = run_leaf(T, k * NB1, span, rs, f, a);
+                    const uint32_t p0 = pack_normal(T, f, a, alive, 0u, 0u);
+                    alive = run_leaf(T, k * NB1 + max_bits, span, rs, f, a);
+                    const uint32_t p1 = (p0 & kPkShared) ? p0 : pack_normal(T, f, a, alive, max_bits, 1u);
+                    row[2 * k] = p0 & ~kPkShared;
+                    row[2 * k + 1] = p1 & ~kPkShared;
+                }
+            }
+            // skip rows.  Skipping ends at `rs`; from there the machine starts in reset -- the normal
+            // row (reset, few bits) of a shorter span when the level before the skip equals the span's, a
+            // special row otherwise.
+            const uint64_t end_const = span.pos0 + span.n, last = end_const + 1;
+            for (uint32_t kk = 0; kk < 2; ++kk) {
+                uint32_t out;
+                if (rs >= last) {
+                    out = SNB + kk;                                 // still skipping when the span ends
+                } else {
+                    const uint64_t n2 = rs >= end_const ? 0 : end_const - rs;
+                    uint32_t pk = 0;
+                    if (n2 <= 0xfffffff0ull) pk = lt_lookup(lt_off, lt_n0, lt_pk, kk == span.L ? 0u : 2 * S + kk, span.L, (uint32_t)n2);
+                    if (pk & kPkAbsolute) {
+                        out = pk & 0xffffu;
+                    } else if (pk & kPkRelative) {
+                        const uint32_t nbo = (pk >> 8) & 0xffffu;       // from a bit count of 0
+                        out = (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                    } else {
+                        PSim f;                                         // position dependent or sensitive
+                        Acc a;
+                        const bool alive = run_leaf(T, SNB + kk, span, rs, f, a);
+                        out = encode_post(T, f, a, alive);
+                    }
+                }
+                row[2 * S + kk] = pack_absolute(out, NB1);
+            }
+        }
+        wave_sync_lds();
+        // ---- which leaves can end stuck (block_sims): those of the block from their rows, the few
+        //      before it (whose stuck codes may enter the block) from the tables ------------------------
+        if (T.NS) {
+            for (uint32_t e = lane; e < count * T.nstuck_rows; e += 64) {
+                const uint32_t l = e / T.nstuck_rows, rl = T.stuck_row[e - l * T.nstuck_rows];
+                if ((rl >> 7) != ((uint32_t)((first + l) & 1ull) ^ T.lvl0)) continue;
+                if (b.res[l * nsim + (rl & 127u)] & kPkStuck) atomicOr(&s_cap[(l + kStuckDepth) >> 5], 1u << ((l + kStuckDepth) & 31u));
+            }
+            for (uint32_t t = lane; t < T.depth * T.nstuck_rows; t += 64) {
+                const uint32_t j = t / T.nstuck_rows + 1, rl = T.stuck_row[t - (j - 1) * T.nstuck_rows];
+                const uint32_t r = rl & 127u;
+                if (first < (uint64_t)j + 1) continue;                  // leaf first - j >= 1
+                const uint64_t i = first - j;
+                if ((rl >> 7) != ((uint32_t)(i & 1ull) ^ T.lvl0)) continue;
+                const uint64_t n = edges[i] - edges[i - 1] - 1;
+                if (n > 0xfffffff0ull) continue;
+                if (lt_lookup(lt_off, lt_n0, lt_pk, r, (uint32_t)(i & 1ull) ^ T.lvl0, (uint32_t)n) & kPkStuck) {
+                    atomicOr(&s_cap[(kStuckDepth - j) >> 5], 1u << ((kStuckDepth - j) & 31u));
+                }
+            }
+            wave_sync_lds();
+        }
+        // ---- chunk tables: every code a span can be entered in at this level, through its chunk ---------
+        {
+            const uint32_t lvl = (uint32_t)(first & 1ull) ^ T.lvl0;        // (a chunk starts on a multiple of 16 leaves)
+            const uint16_t *lv = sp.reach ? sp.reach + sp.nreach + (lvl ? sp.nreach_lv[0] : 0u) : nullptr;
+            const uint32_t NR = sp.reach ? sp.nreach_lv[lvl] : D0;
+            const uint32_t nitem = nch * NR;
+            uint32_t base = 0;
+            while (base < nitem) {
+                const uint32_t left = (nitem - base + 63u) / 64u;
+                if (left >= 8) {
+                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base += 8 * 64;
+                } else if (left > 5) {
+                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
+                } else if (left > 3) {
+                    wave_compose<5>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
+                } else if (left > 1) {
+                    wave_compose<3>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
+                } else {
+                    wave_compose<1>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
+                }
+            }
+            // chains that START in a stuck code: only behind a leaf that can end stuck -- nowhere in a clean capture
+            bool any = false;
+            for (uint32_t w = 0; w < kCapWords; ++w) any = any || s_cap[w] != 0;
+            if (any && T.NS) {
+                const uint32_t nst = T.NS * T.depth;
+                for (uint32_t item = lane; item < nch * nst; item += 64) {
+                    const uint32_t c = item / nst, code = D0 + (item - c * nst);
+                    const uint32_t la = c * kChunk, lbb = min((c + 1) * (uint32_t)kChunk, count);
+                    // STUCK_d enters the chunk only if the leaf d before it can end stuck
+                    const uint32_t ob = la + kStuckDepth - ((code - D0) / T.NS + 1);
+                    if (!(s_cap[ob >> 5] & (1u << (ob & 31u)))) continue;
+                    uint32_t v = code;
+                    for (uint32_t l = la; l < lbb; ++l) v = wave_step_slow(T, sc, edges, first, l, b.res, s_resume, v);
+                    b.ctab[c * D + code] = (uint16_t)v;
+                }
+            }
+            wave_sync_lds();
+        }
+        // ---- the block's table: every abstract state walks the chunk tables ------------------------------
+        for (uint32_t d = lane; d < D; d += 64) {
+            uint32_t s = d;
+            for (uint32_t c = 0; c < nch; ++c) s = b.ctab[c * D + s];
+            sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
+        }
+        wave_sync_lds();
     }
 }
 
@@ -1461,13 +1869,25 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         const uint64_t *edges = sp.f.edges + e0;
         const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
         uint32_t s = sp.blk_in[gb];
-        uint16_t *pre = sp.pre_codes + e0 + cap + first;
+        // eight leaves at a time: their edges in one go (one memory latency per eight steps, not per step),
+        // their codes in one 16-byte store (block-major list: 2 * LB bytes per block, aligned)
+        uint4 *pre = reinterpret_cast<uint4 *>(sp.pre_codes + (size_t)gb * LB);
         uint64_t before = edges[first - 1];
-        for (uint32_t l = 0; l < count; ++l) {
-            pre[l] = (uint16_t)s;
-            const uint64_t at = edges[first + l];
-            s = leaf_step_fly(T, sc, first + l, before, at, s);
-            before = at;
+        for (uint32_t l0 = 0; l0 < count; l0 += 8) {
+            uint64_t ev[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) ev[k] = edges[first + min(l0 + k, count - 1)];
+            uint32_t code[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                code[k] = s;
+                if (l0 + k < count) {
+                    s = leaf_step_fly(T, sc, first + l0 + k, before, ev[k], s);
+                    before = ev[k];
+                }
+            }
+            pre[l0 >> 3] = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16), code[4] | (code[5] << 16),
+                                      code[6] | (code[7] << 16));
         }
     }
 }
@@ -1499,7 +1919,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             // the leaves' entry codes are there already (scan_entry_kernel): no table is staged
             for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
                 s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
-                pre[l] = sp.pre_codes[e0 + cap + first + l];
+                pre[l] = sp.pre_codes[(size_t)w * LB + l];
             }
             __syncthreads();
             // a wavefront takes the leaves entered in "its" states (state mod 16; skip
@@ -1983,6 +2403,11 @@ void fill_ltab_host(LTab &T, const FsmTablesDev &g, uint32_t spb, uint32_t decim
     T.D = g.num_states * (g.max_bits + 2) + 3;
     T.spb = spb;
     T.decim = decim;
+    T.buf_shift = 0xffffffffu;
+    if (decim && spb % decim == 0) {
+        const uint32_t q = spb / decim;
+        if (q && !(q & (q - 1))) T.buf_shift = (uint32_t)__builtin_ctz(q);
+    }
     T.NS = 0;
     T.nstuck_rows = 0;
     T.depth = 0;
@@ -2302,6 +2727,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.reach = a.first ? nullptr : a.reach;
     sp.nreach = a.first ? 0 : a.nreach;
     sp.nreach_base = a.first ? 0 : a.nreach_base;
+    sp.nreach_lv[0] = a.nreach_lv[0];
+    sp.nreach_lv[1] = a.nreach_lv[1];
     sp.Dp = (a.D + 7u) & ~7u;
     sp.D = a.D;
     sp.cap_group_off = a.cap_group_off;
@@ -2318,12 +2745,38 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     if (e != hipSuccess) return e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_walk_kernel), lds_walk);
     if (e != hipSuccess) return e;
+    // with span tables and 64-leaf blocks the leaf kernel runs one wave per block (OOKD_SCAN_LEAF=block: the
+    // workgroup-per-block form, which is also what runs without span tables)
+    const char *const leaf_env = getenv("OOKD_SCAN_LEAF");       // (looked up per launch: the tests switch it)
+    const size_t lds_wave = wave_lds_bytes(a.D, a.S);
+    const bool wave_form = a.lt_off && a.leaf_block == 64 && lds_wave <= 60u * 1024u && !(leaf_env && leaf_env[0] == 'b');
+    if (wave_form) {
+        e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_leaf_wave_kernel), lds_wave);
+        if (e != hipSuccess) return e;
+    }
     const uint32_t caps = a.f.num_captures;
     const uint32_t cap_grid = caps < 256 ? caps : 256;
     // leaf / emit are persistent grids: exactly as many workgroups as the chip holds at once (a
     // second, thinner round of the 1024 there used to be cost a third of their time)
     static thread_local int sim_dev = -1;
-    static thread_local uint32_t leaf_grid = 0, emit_grid = 0;
+    static thread_local uint32_t leaf_grid = 0, emit_grid = 0, wave_grid = 0;
+    static thread_local size_t wave_lds_seen = ~(size_t)0;
+    if (wave_form) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev != sim_dev || lds_wave != wave_lds_seen) {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_leaf_wave_kernel, 64, lds_wave) == hipSuccess &&
+                hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 && per_cu > 0) {
+                wave_grid = (uint32_t)(per_cu * prop.multiProcessorCount);
+            } else {
+                (void)hipGetLastError();
+                wave_grid = 4 * a.grid_blocks;
+            }
+            wave_lds_seen = lds_wave;
+        }
+    }
     static thread_local size_t sim_lds = 0;
     {
         int dev = 0;
@@ -2349,7 +2802,11 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     const uint32_t leaf_blocks = grid_env ? (uint32_t)atoi(grid_env) : leaf_grid;
     const uint32_t emit_blocks = grid_env ? (uint32_t)atoi(grid_env) : emit_grid;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
-    hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
+    if (wave_form) {
+        hipLaunchKernelGGL(scan_leaf_wave_kernel, dim3(grid_env ? (uint32_t)atoi(grid_env) : wave_grid), dim3(64), lds_wave, stream, sp);
+    } else {
+        hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
+    }
     hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
     // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables

@@ -295,6 +295,7 @@ struct FsmScanArgs {
     PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
     const uint16_t *reach;      // codes a span can be entered in (ascending), or null = all
     uint32_t nreach, nreach_base;       // all / those below the stuck codes (S * (max_bits + 2) + 3)
+    uint32_t nreach_lv[2];      // behind the nreach entries: the codes met at level 0, then those met at level 1
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]
@@ -309,7 +310,7 @@ struct FsmScanArgs {
     const uint64_t *totals_in;  // [2] messages / errors of the chunks before (device)
     const uint32_t *edge_overflow;      // the edge stage's overflow flag (device), or null
     uint32_t *cap_fallback;     // [captures] per-capture refusal bits (zero at launch), or null
-    uint16_t *pre_codes;        // [edges + captures] entry code of every leaf (scan_entry_kernel)
+    uint16_t *pre_codes;        // [total_blocks_cap][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [total_blocks_cap] entry code of every block
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path

@@ -339,6 +339,8 @@ struct ookd_rx {
     bool pending_first_valid = false;
     FsmStateDev pending_first{};
     uint32_t scan_reach_base = 0;   // reach entries below the stuck codes
+    uint32_t scan_reach_n = 0;      // reach entries; behind them the per-level lists (scan_reach_lv[level] codes each)
+    uint32_t scan_reach_lv[2] = {0, 0};
     uint32_t scan_D = 0, scan_S = 0, scan_leaf_block = 0, scan_blocks_cap = 0;
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab;
@@ -743,8 +745,10 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.lt_pk = d_lt_pk.p;
         a.ltab = d_ltab.p;
         a.reach = d_reach.p;
-        a.nreach = (uint32_t)d_reach.n;
+        a.nreach = scan_reach_n;
         a.nreach_base = scan_reach_base;
+        a.nreach_lv[0] = scan_reach_lv[0];
+        a.nreach_lv[1] = scan_reach_lv[1];
         if (last) {
             a.publish = publish_params();
             a.publish.total_edges = nullptr;        // accumulated in the header by the edge stages
@@ -1050,8 +1054,10 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_pk = d_lt_pk.p;
     a.ltab = d_ltab.p;
     a.reach = d_reach.p;
-    a.nreach = (uint32_t)d_reach.n;
+    a.nreach = scan_reach_n;
     a.nreach_base = scan_reach_base;
+    a.nreach_lv[0] = scan_reach_lv[0];
+    a.nreach_lv[1] = scan_reach_lv[1];
     a.publish = publish_params();
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
@@ -1087,14 +1093,23 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     static const char *const debug_scan = getenv("OOKD_DEBUG_SCAN");     // read once: this is the hot path
     if (debug_scan) HIPCHK(hipStreamSynchronize(stream));
     if (debug_scan && d_debug.p) {
-        uint64_t dbg[48];
+        uint64_t dbg[64];
         HIPCHK(hipMemcpy(dbg, d_debug.p, sizeof(dbg), hipMemcpyDeviceToHost));
         fprintf(stderr, "[scan] block_sims phases: resume %llu gap+rep %llu uniq %llu sims %llu\n",
                 (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
                 (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
-        fprintf(stderr, "[scan] compose phases: fill %llu setup %llu chains %llu finish %llu\n",
-                (unsigned long long)(dbg[33] - dbg[32]), (unsigned long long)(dbg[34] - dbg[33]),
-                (unsigned long long)(dbg[35] - dbg[34]), (unsigned long long)(dbg[36] - dbg[35]));
+        {
+            const uint64_t *c = dbg + 48;       // compose_chunks' stamps
+            fprintf(stderr, "[scan] compose phases: fill %llu setup %llu chains %llu (first leaf %llu, distinct list %llu, walk of %llu of %llu "
+                            "codes %llu, pick-up %llu) finish %llu\n",
+                    (unsigned long long)(c[1] - c[0]), (unsigned long long)(c[2] - c[1]), (unsigned long long)(c[3] - c[2]),
+                    (unsigned long long)(c[5] - c[2]), (unsigned long long)(c[6] - c[5]), (unsigned long long)(c[9] & 0xffffffffu),
+                    (unsigned long long)(c[9] >> 32), (unsigned long long)(c[7] - c[6]), (unsigned long long)(c[3] - c[7]),
+                    (unsigned long long)(c[4] - c[3]));
+            fprintf(stderr, "[scan] compose: dedupe %llu slabs %llu NR %llu scratch words %llu per wave %llu\n", (unsigned long long)(c[8] & 1),
+                    (unsigned long long)((c[8] >> 4) & 0xfff), (unsigned long long)((c[8] >> 16) & 0xffff),
+                    (unsigned long long)((c[8] >> 32) & 0xffff), (unsigned long long)(c[8] >> 48));
+        }
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans, cap %llx\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
@@ -1504,6 +1519,20 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 const uint32_t d0 = rx->scan_S * (device->num_bits + 2) + 3;
                 rx->scan_reach_base = 0;                // entries are code | level mask << 14, ascending in the code
                 for (uint16_t v : reach) rx->scan_reach_base += (v & 0x3fffu) < d0 ? 1u : 0u;
+                // ... then, for the composition of chunk tables, the codes met at level 0 and those met at
+                // level 1 as two plain lists (a chunk starts at one level: only that list is walked)
+                rx->scan_reach_n = (uint32_t)reach.size();
+                {
+                    std::vector<uint16_t> l0, l1;
+                    for (uint32_t i = 0; i < rx->scan_reach_base; ++i) {
+                        if (reach[i] & 0x4000u) l0.push_back((uint16_t)(reach[i] & 0x3fffu));
+                        if (reach[i] & 0x8000u) l1.push_back((uint16_t)(reach[i] & 0x3fffu));
+                    }
+                    rx->scan_reach_lv[0] = (uint32_t)l0.size();
+                    rx->scan_reach_lv[1] = (uint32_t)l1.size();
+                    reach.insert(reach.end(), l0.begin(), l0.end());
+                    reach.insert(reach.end(), l1.begin(), l1.end());
+                }
                 rc |= rx->d_reach.alloc(reach.size());
                 if (rc == OOKD_OK && hipMemcpy(rx->d_reach.p, reach.data(), reach.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
                     rc = OOKD_ERR_HIP;
@@ -1545,7 +1574,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
-            rc |= rx->d_pre.alloc(rx->edge_capacity + caps + 8);
+            rc |= rx->d_pre.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
