@@ -1183,7 +1183,6 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
     const uint32_t per_wave = set_words + (64u * kIlp + 1u) / 2u;
     const bool dedupe = slabs == 1 && set_words <= 64u && per_wave * nwaves <= scratch_words;
     uint32_t *seen = scratch + wave * per_wave;
-    if (dbg && threadIdx.x == 0) dbg[8] = (dedupe ? 1u : 0u) | (slabs << 4) | ((uint64_t)NR << 16) | ((uint64_t)scratch_words << 32) | ((uint64_t)per_wave << 48);
     uint16_t *list = reinterpret_cast<uint16_t *>(seen + set_words);
     for (uint32_t unit = wave; unit < nch * slabs; unit += nwaves) {
         const uint32_t c = unit / slabs, slab = unit - c * slabs;
@@ -1203,7 +1202,6 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
             compose_walk<kIlp>(T, sc, first, b, SNB, rep, skip, l0, l1, st);
         } else {
             compose_walk<kIlp>(T, sc, first, b, SNB, rep, skip, l0, l0 + 1, st);
-            STAMP(5);
             // ---- the distinct base codes among st[] ---------------------------------------------
             if (lane < set_words) seen[lane] = 0;
             wave_sync_lds();
@@ -1227,8 +1225,6 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
                 list[at++] = (uint16_t)(lane * 32u + bit);
             }
             wave_sync_lds();
-            STAMP(6);
-            if (dbg && threadIdx.x == 0) dbg[9] = nd | ((uint64_t)NR << 32);
             // ---- they walk the rest of the chunk; results parked in the chunk's own row -----------
             for (uint32_t base = 0; base < nd; base += 64u * kIlp) {
                 uint32_t ds[kIlp], dv[kIlp];
@@ -1244,7 +1240,6 @@ __device__ void compose_chunks(const LTab &T, const StuckCtx &sc, uint64_t first
                     if (base + (uint32_t)j * 64u + lane < nd) row[dv[j]] = (uint16_t)ds[j];
             }
             wave_sync_lds();
-            STAMP(7);
             // ---- every code picks up the result of the state its first leaf led to ------------------
             uint32_t stuck1 = 0;
 #pragma unroll
@@ -1439,18 +1434,18 @@ __global__ __launch_bounds__(kSimThreads) void scan_leaf_kernel(ScanParams sp) {
 // barrier anywhere, a dozen blocks per CU at a time.  The block tables are the same bit for bit.
 
 struct WaveLds {
-    uint32_t *res;      // [64][2S+2]
+    uint32_t *res;      // [64][2S+4]: (state, class) rows, skip 0, skip 1, poison, spare
     uint16_t *ctab;     // [64 / kChunk][D]
 };
 __host__ __device__ __forceinline__ size_t wave_lds_bytes(uint32_t D, uint32_t S) {
-    return (size_t)64 * (2 * S + 2) * 4 + ((size_t)(64 / kChunk) * D * 2 + 15) / 16 * 16;
+    return (size_t)64 * (2 * S + 4) * 4 + ((size_t)(64 / kChunk) * D * 2 + 15) / 16 * 16;
 }
 
 // one step of the slow path: everything leaf_step_fly knows, from the block's packed rows
 __device__ __noinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
                                                 uint32_t l, const uint32_t *res, const uint64_t *resume, uint32_t s) {
     const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
-    const uint32_t *row = res + l * (2 * S + 2);
+    const uint32_t *row = res + l * (2 * S + 4);
     if (s >= SNB) {
         if (s < SNB + 2) return row[2 * S + (s - SNB)] & 0xffffu;
         return s == SNB + 2 ? s : stuck_step(T, sc, first + l, s);
@@ -1469,68 +1464,87 @@ __device__ __noinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &s
     return encode_post(T, f, a, alive);
 }
 
-// K chains per lane, each through the leaves la[j] .. lb[j]-1 of the block
+// K chains per lane, each through the 16 leaves of its chunk (a short last chunk is padded with identity rows).
+// A chain's state is kept as (state, bit count) -- skip / poison codes as state S with "bit count" 0 / 1 / 2,
+// so that code = state * NB1 + bit count throughout -- which is what the packed rows are made of: no division
+// per step, every product fits 24 bits.  Rows are 2S + 4 words: (state, class) pairs, skip 0, skip 1, poison
+// (-> poison), spare.  A row that is neither absolute nor relative (stuck, bit-count sensitive, position
+// dependent) is walked as if it were relative -- garbage, but inside the tables -- and flags the chain, which is
+// then redone from its start by the slow path.  ~22 instructions per chain and step.
 template <int K>
-__device__ __forceinline__ void wave_walk(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
-                                          const uint32_t *res, const uint64_t *resume, uint32_t nsim, uint32_t rcpNB1,
-                                          const uint32_t (&la)[K], const uint32_t (&lb)[K], uint32_t (&st)[K]) {
-    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, max_bits = T.max_bits;
-    uint32_t stop[K];           // leaf at which the chain left the fast path (lb: it did not)
-#pragma unroll
-    for (int j = 0; j < K; ++j) stop[j] = lb[j];
-    for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
-        uint32_t pk[K], nb[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t v = st[j], l = la[j] + step;
-            const uint32_t cur = __umulhi(v, rcpNB1);           // v / NB1 (exact below 2^16)
-            nb[j] = v - cur * NB1;
-            const uint32_t col = v < SNB ? 2u * cur + (nb[j] >= max_bits ? 1u : 0u) : 2u * S + (v == SNB + 1 ? 1u : 0u);
-            pk[j] = res[(l < lb[j] ? l : la[j]) * nsim + col];
-        }
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const uint32_t v = st[j], l = la[j] + step;
-            const uint32_t nbo = nb[j] + ((pk[j] >> 8) & 0xffffu);
-            const uint32_t rel = (pk[j] & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
-            const uint32_t fast = (pk[j] & kPkAbsolute) ? (pk[j] & 0xffffu) : rel;
-            const bool live = l < lb[j] && stop[j] == lb[j] && v < SNB + 2;      // poison (SNB + 2) stays
-            const bool ok = (pk[j] & (kPkAbsolute | kPkRelative)) != 0;
-            st[j] = (live && ok) ? fast : v;
-            stop[j] = (live && !ok) ? l : stop[j];
-        }
-    }
+__device__ __forceinline__ void wave_walk(const LTab &T, const uint32_t *res, uint32_t nsim, uint32_t rcpNB1,
+                                          const uint32_t (&la)[K], uint32_t (&st)[K], uint32_t &trapped) {
+    const uint32_t S = T.S, NB1 = T.NB1, max_bits = T.max_bits;
+    uint32_t cur[K], nb[K], ro[K], good[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        for (uint32_t l = stop[j]; l < lb[j]; ++l) st[j] = wave_step_slow(T, sc, edges, first, l, res, resume, st[j]);
+        cur[j] = __umulhi(st[j], rcpNB1);                       // st / NB1 (exact below 2^16), once per chain
+        nb[j] = st[j] - cur[j] * NB1;
+        ro[j] = __umul24(la[j], nsim);
+        good[j] = 0x80000000u;
+    }
+    for (uint32_t step = 0; step < (uint32_t)kChunk; ++step) {
+        uint32_t pk[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t col = cur[j] < S ? 2u * cur[j] + (nb[j] >= max_bits ? 1u : 0u) : 2u * S + (nb[j] & 3u);
+            pk[j] = res[ro[j] + col];
+            ro[j] += nsim;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint32_t p = pk[j];
+            const uint32_t acur = (p >> 16) & 0xffu;                                    // absolute: the end code's state
+            const uint32_t anb = (p & 0xffffu) - __umul24(acur, NB1);
+            const uint32_t rnb = min(nb[j] + ((p >> 8) & 0xffffu), NB1 - 1u);           // relative: bits appended
+            const bool isabs = (int32_t)p < 0;                                          // kPkAbsolute = bit 31
+            good[j] &= p | (p << 2);                                                    // bit 31 | bit 29 (kPkRelative)
+            cur[j] = isabs ? acur : (p & 0xffu);
+            nb[j] = isabs ? anb : rnb;
+        }
+    }
+    trapped = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        st[j] = __umul24(cur[j], NB1) + nb[j];
+        trapped |= (good[j] & 0x80000000u) ? 0u : 1u << j;
     }
 }
+static_assert(kPkAbsolute == 0x80000000u && kPkRelative == 0x20000000u, "wave_walk tests these bits by position");
 
 template <int K>
 __device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
                                              const WaveLds &b, const uint64_t *resume, uint32_t D, uint32_t count,
                                              const uint16_t *reach_lv, uint32_t NR, uint32_t rcpNB1, uint32_t base) {
-    const uint32_t SNB = T.S * T.NB1, nsim = 2 * T.S + 2;
+    const uint32_t nsim = 2 * T.S + 4;
     const uint32_t nch = (count + kChunk - 1) / kChunk, nitem = nch * NR;
     const uint32_t lane = threadIdx.x;
-    uint32_t la[K], lb[K], st[K], dst[K];
+    uint32_t la[K], st[K], code[K], dst[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const uint32_t item = base + (uint32_t)j * 64u + lane;
         const bool valid = item < nitem;
         const uint32_t it = valid ? item : 0u;
         const uint32_t c = it / NR, idx = it - c * NR;
-        const uint32_t code = reach_lv ? (uint32_t)reach_lv[idx] : idx;
+        code[j] = reach_lv ? (uint32_t)reach_lv[idx] : idx;
         la[j] = c * kChunk;
-        lb[j] = valid ? min((c + 1) * (uint32_t)kChunk, count) : la[j];
-        st[j] = code;
-        dst[j] = valid ? c * D + code : 0xffffffffu;
+        st[j] = code[j];
+        dst[j] = valid ? c * D + code[j] : 0xffffffffu;
     }
-    wave_walk<K>(T, sc, edges, first, b.res, resume, nsim, rcpNB1, la, lb, st);
+    uint32_t trapped;
+    wave_walk<K>(T, b.res, nsim, rcpNB1, la, st, trapped);
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (dst[j] != 0xffffffffu) b.ctab[dst[j]] = (uint16_t)st[j];
-    (void)SNB;
+    for (int j = 0; j < K; ++j) {
+        if (dst[j] == 0xffffffffu) continue;
+        if ((trapped >> j) & 1u) {
+            // met a row the fast walk does not know: again from the start, one full step at a time
+            uint32_t v = code[j];
+            const uint32_t lb = min(la[j] + (uint32_t)kChunk, count);
+            for (uint32_t l = la[j]; l < lb; ++l) v = wave_step_slow(T, sc, edges, first, l, b.res, resume, v);
+            st[j] = v;
+        }
+        b.ctab[dst[j]] = (uint16_t)st[j];
+    }
 }
 
 __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
@@ -1545,7 +1559,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
     wave_sync_lds();
     if (*sp.fallback) return;
     const uint32_t lane = threadIdx.x;
-    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D, nsim = 2 * S + 2, max_bits = T.max_bits;
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D, nsim = 2 * S + 4, max_bits = T.max_bits;
     const uint32_t D0 = SNB + 3;
     const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + NB1 - 1) / NB1);
     WaveLds b;
@@ -1554,7 +1568,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
     // the span tables are searched from LDS when they fit (the shipped devices: 409 words)
     const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
     {
-        const uint32_t noff = 2 * nsim + 1, nint = lt_off[noff - 1];
+        const uint32_t noff = 2 * (2 * S + 2) + 1, nint = lt_off[noff - 1];
         if (noff + 2 * nint <= kLtLdsWords) {
             for (uint32_t i = lane; i < noff; i += 64) s_lt[i] = sp.lt_off[i];
             for (uint32_t i = lane; i < nint; i += 64) {
@@ -1592,6 +1606,8 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
         const uint32_t nch = (count + kChunk - 1) / kChunk;
+        uint64_t *dbg = (sp.f.debug && gb == 2) ? sp.f.debug + 48 : nullptr;
+        STAMP(0);
         // ---- lane l = leaf l: its packed rows --------------------------------------------------
         if (lane < kCapWords) s_cap[lane] = 0;
         for (uint32_t i = lane; i < nch * D; i += 64) b.ctab[i] = (uint16_t)(SNB + 2);
@@ -1648,8 +1664,17 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
                 }
                 row[2 * S + kk] = pack_absolute(out, NB1);
             }
+            row[2 * S + 2] = row[2 * S + 3] = pack_absolute(SNB + 2, NB1);
+        } else if (lane < nch * kChunk) {
+            // padding of a short last chunk: identity rows (the fast walk always takes 16 steps)
+            uint32_t *row = b.res + lane * nsim;
+            for (uint32_t k = 0; k < S; ++k) row[2 * k] = row[2 * k + 1] = k | kPkRelative;
+            row[2 * S] = pack_absolute(SNB, NB1);
+            row[2 * S + 1] = pack_absolute(SNB + 1, NB1);
+            row[2 * S + 2] = row[2 * S + 3] = pack_absolute(SNB + 2, NB1);
         }
         wave_sync_lds();
+        STAMP(1);
         // ---- which leaves can end stuck (block_sims): those of the block from their rows, the few
         //      before it (whose stuck codes may enter the block) from the tables ------------------------
         if (T.NS) {
@@ -1672,6 +1697,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
             }
             wave_sync_lds();
         }
+        STAMP(2);
         // ---- chunk tables: every code a span can be entered in at this level, through its chunk ---------
         {
             const uint32_t lvl = (uint32_t)(first & 1ull) ^ T.lvl0;        // (a chunk starts on a multiple of 16 leaves)
@@ -1698,6 +1724,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
                     base = nitem;
                 }
             }
+            STAMP(3);
             // chains that START in a stuck code: only behind a leaf that can end stuck -- nowhere in a clean capture
             bool any = false;
             for (uint32_t w = 0; w < kCapWords; ++w) any = any || s_cap[w] != 0;
@@ -1716,6 +1743,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
             }
             wave_sync_lds();
         }
+        STAMP(4);
         // ---- the block's table: every abstract state walks the chunk tables ------------------------------
         for (uint32_t d = lane; d < D; d += 64) {
             uint32_t s = d;
@@ -1723,6 +1751,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
             sp.block_tab[(size_t)gb * sp.Dp + d] = (uint16_t)s;
         }
         wave_sync_lds();
+        STAMP(5);
     }
 }
 

@@ -1099,16 +1099,10 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
                 (unsigned long long)(dbg[41] - dbg[40]), (unsigned long long)(dbg[42] - dbg[41]),
                 (unsigned long long)(dbg[43] - dbg[42]), (unsigned long long)(dbg[44] - dbg[43]));
         {
-            const uint64_t *c = dbg + 48;       // compose_chunks' stamps
-            fprintf(stderr, "[scan] compose phases: fill %llu setup %llu chains %llu (first leaf %llu, distinct list %llu, walk of %llu of %llu "
-                            "codes %llu, pick-up %llu) finish %llu\n",
+            const uint64_t *c = dbg + 48;       // the leaf kernel's stamps (block 2)
+            fprintf(stderr, "[scan] leaf (wave form) block 2: rows %llu stuck marks %llu compose %llu stuck starts %llu block table %llu ticks\n",
                     (unsigned long long)(c[1] - c[0]), (unsigned long long)(c[2] - c[1]), (unsigned long long)(c[3] - c[2]),
-                    (unsigned long long)(c[5] - c[2]), (unsigned long long)(c[6] - c[5]), (unsigned long long)(c[9] & 0xffffffffu),
-                    (unsigned long long)(c[9] >> 32), (unsigned long long)(c[7] - c[6]), (unsigned long long)(c[3] - c[7]),
-                    (unsigned long long)(c[4] - c[3]));
-            fprintf(stderr, "[scan] compose: dedupe %llu slabs %llu NR %llu scratch words %llu per wave %llu\n", (unsigned long long)(c[8] & 1),
-                    (unsigned long long)((c[8] >> 4) & 0xfff), (unsigned long long)((c[8] >> 16) & 0xffff),
-                    (unsigned long long)((c[8] >> 32) & 0xffff), (unsigned long long)(c[8] >> 48));
+                    (unsigned long long)(c[4] - c[3]), (unsigned long long)(c[5] - c[4]));
         }
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans, cap %llx\n", i,
