@@ -1010,3 +1010,46 @@ def test_submit_wait_two_contexts(ok, oracle, vectors):
             assert (r.payloads == want.payloads).all()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("filt,leaf_form", [("fs128_fs16_dec4", None), ("fs32_fs4", None), ("fs128_fs16_dec4", "block")])
+def test_fresh_contexts_and_shards_repeat_exactly(ok, oracle, vectors, filt, leaf_form, monkeypatch):
+    """The same capture through a dozen freshly made contexts, whole and as two shards (halo, carried state,
+    refine): every one of them must give the oracle's messages.  Fresh contexts get fresh (dirty) device
+    memory and their kernels land wherever the chip has room, so anything read before it is written, or
+    depending on which workgroup took which block, shows up here as a run that differs from its
+    neighbours.  leaf_form "block": the scan's workgroup-per-block leaf kernel (what runs without span
+    tables), otherwise the wave-per-block one."""
+    from ookiedokie_amd.distributed import shard_bounds
+    if leaf_form:
+        monkeypatch.setenv("OOKD_SCAN_LEAF", leaf_form)
+    g, iq = _g1(vectors, noise_seed=21)
+    n = iq.size // 2
+    import torch
+    f = _flt(ok, filt)
+    rate = RATE // f.total_decimation
+    d = ok.Device.load(golden_path("devices", "p3l-nexa2012"), rate)
+    od = oracle.load_device_json(golden_path("devices", "p3l-nexa2012"), rate)[0]
+    want = oracle.rx(iq, _ofir(oracle, filt), 0.1, od, 8192)
+    want_msgs = [int(s) for s in want.msg_samples]
+    assert len(want_msgs) == 3
+    cap = torch.from_numpy(iq.copy()).cuda()
+    b = shard_bounds(n, 2, 8192, f.total_decimation)
+    for it in range(12):
+        rxw = ok.Receiver(f, d, max_samples=n, samples_per_buffer=8192)
+        whole = rxw.rx_device(cap.data_ptr(), n)
+        assert [int(s) for s in whole.msg_samples] == want_msgs, (it, "whole")
+        assert (whole.payloads == want.payloads).all()
+        rxw.close()
+        rx0 = ok.Receiver(f, d, max_samples=b[1], samples_per_buffer=8192)
+        rx1 = ok.Receiver(f, d, max_samples=n - b[1], samples_per_buffer=8192)
+        H = rx0.halo_samples
+        r0, s0 = rx0.shard_begin(cap.data_ptr(), b[1], None, False, None)
+        halo = cap[2 * (b[1] - H):2 * b[1]]
+        r1, s1 = rx1.shard_begin(cap.data_ptr() + 4 * b[1], n - b[1], halo, True, None)
+        if bytes(s0) != bytes(ok.FsmState()):
+            r1, s1 = rx1.shard_refine(s0)
+        got = [int(x) for x in r0.msg_samples] + [int(x) + b[1] // f.total_decimation for x in r1.msg_samples]
+        assert got == want_msgs, (it, "sharded", r0.stats["fsm_path"], r1.stats["fsm_path"])
+        rx0.close()
+        rx1.close()
