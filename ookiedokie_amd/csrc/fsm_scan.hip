@@ -489,6 +489,7 @@ struct ScanParams {
     // entry code of every leaf (scan_entry_kernel): the emit kernel then needs none of the tables
     uint16_t *pre_codes;        // [blocks][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [blocks] entry code of every block
+    uint16_t *rowz;             // [blocks][leaf_block] merged-rows interval of every leaf (0xffff: span too long for the tables)
     uint32_t entry_phase;       // scan_entry_kernel: 0 groups -> blocks, 1 blocks -> chunks -> leaves
     uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
                                 // capture whose path leaves the model is left out of the results -- the host
@@ -509,6 +510,9 @@ struct ScanParams {
     const uint16_t *reach;      // abstract codes a span can be entered in (from the span tables), or null = all
     uint32_t nreach, nreach_base;       // all of them / the normal, skip and poison codes among them (they come first)
     uint32_t nreach_lv[2];              // reach + nreach: the base codes met at level 0, then those met at level 1
+    uint32_t lt_words;                  // size of the span tables (offsets + 2 x intervals)
+    const uint32_t *lt_merged;          // build_merged_rows of the span tables, or null
+    uint32_t lt_merged_words;
     uint32_t Dp, D;             // block table row pitch (D rounded up to 8); D = the domain with the stuck codes
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
@@ -659,6 +663,7 @@ __device__ __forceinline__ Span span_entered(const LTab &T, const uint64_t *edge
 
 constexpr uint32_t kCapWords = (256 + kStuckDepth + 31) / 32;
 constexpr uint32_t kLtLdsWords = 768;   // span tables up to this size are searched from LDS (shipped devices: 409)
+constexpr uint32_t kMergedLdsWords = 3072;      // merged rows up to this size are read from LDS (scan_entry_kernel)
 #define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 // cap: bit kStuckDepth + l = leaf l of the block (l = -kStuckDepth .. count-1) can end stuck
 __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
@@ -1834,6 +1839,70 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
     }
 }
 
+// LDS copies of the span tables and the merged rows for scan_entry_kernel, at file scope: the out-of-line step
+// function below reads them as the LDS arrays they are.  (Through a pointer that may also point to global
+// memory every read of a table search is a FLAT load at twice the latency, and a step of the walk is a dozen
+// dependent reads: 1.8 us per step, 115 us for the pass; `tools`-less experiment in DESIGN.md 4.6a.)
+__shared__ uint32_t g_lt[kLtLdsWords];          // offsets [noff] | n0 [nint] | pk [nint]
+__shared__ uint32_t g_mr[kMergedLdsWords];
+
+__device__ __forceinline__ uint32_t lt_lookup_g(uint32_t noff, uint32_t nint, uint32_t row, uint32_t L, uint32_t n) {
+    uint32_t lo = g_lt[2 * row + L], hi = g_lt[2 * row + L + 1];
+    if (lo >= hi) return 0u;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g_lt[noff + mid] <= n) lo = mid;
+        else hi = mid;
+    }
+    return g_lt[noff + nint + lo];
+}
+
+// leaf_step_fly with the span tables in g_lt (stuck codes and simulations: the generic functions, through sc)
+__device__ __noinline__ uint32_t leaf_step_fly_g(const LTab &T, const StuckCtx &sc, uint32_t noff, uint32_t nint, uint64_t i,
+                                                 uint64_t e_before, uint64_t e_at, uint32_t s) {
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
+    if (s == SNB + 2) return s;                                 // poison stays
+    if (s > SNB + 2) return stuck_step(T, sc, i, s);
+    Span span;
+    span.pos0 = e_before + 1;
+    span.n = e_at - e_before - 1;
+    span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
+    span.has_edge = true;
+    span.prefix = 0;
+    const uint64_t resume = next_buffer_start(T, e_before);
+    if (s < SNB) {
+        if (span.n <= 0xfffffff0ull) {
+            const uint32_t cur = s / NB1, nb = s - cur * NB1;
+            const uint32_t p0 = lt_lookup_g(noff, nint, 2 * cur, span.L, (uint32_t)span.n);
+            uint32_t pk = p0 & ~kPkShared;
+            if (!(p0 & kPkShared) && nb >= T.max_bits) pk = lt_lookup_g(noff, nint, 2 * cur + 1, span.L, (uint32_t)span.n);
+            if (pk & kPkAbsolute) return pk & 0xffffu;
+            if (pk & kPkRelative) {
+                const uint32_t nbo = nb + ((pk >> 8) & 0xffffu);
+                return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+            }
+            if (pk & kPkStuck) return stuck_enter(T, sc, s);
+        }
+    } else {
+        const uint32_t kk = s - SNB;
+        const uint64_t end_const = span.pos0 + span.n, last = end_const + 1;
+        if (resume >= last) return s;                            // still skipping when the span ends
+        const uint64_t n2 = resume >= end_const ? 0 : end_const - resume;
+        if (n2 <= 0xfffffff0ull) {
+            const uint32_t pk = lt_lookup_g(noff, nint, kk == span.L ? 0u : 2 * S + kk, span.L, (uint32_t)n2);
+            if (pk & kPkAbsolute) return pk & 0xffffu;
+            if (pk & kPkRelative) {
+                const uint32_t nbo = (pk >> 8) & 0xffffu;       // from a bit count of 0
+                return (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+            }
+        }
+    }
+    PSim f;
+    Acc a;
+    const bool alive = run_leaf(T, s, span, resume, f, a);
+    return encode_post(T, f, a, alive);
+}
+
 // The entry code of every leaf, exactly, from what leaf / groups / walk left behind -- in two small
 // lane-parallel passes instead of inside every emit workgroup (where thread 0 walked up to 15 block
 // tables and 4 chunk tables and 4 threads 16 leaves each, behind the staging of all those tables:
@@ -1870,25 +1939,58 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         }
         return;
     }
-    // the span tables (a few hundred words for the shipped devices) are searched from LDS
-    __shared__ uint32_t s_lt[kLtLdsWords];
-    const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
-    if (lt_off) {
-        const uint32_t noff = 2 * (2 * T.S + 2) + 1, nint = lt_off[noff - 1];
-        if (noff + 2 * nint <= kLtLdsWords) {
-            for (uint32_t i = threadIdx.x; i < noff; i += blockDim.x) s_lt[i] = sp.lt_off[i];
-            for (uint32_t i = threadIdx.x; i < nint; i += blockDim.x) {
-                s_lt[noff + i] = sp.lt_n0[i];
-                s_lt[noff + nint + i] = sp.lt_pk[i];
-            }
-            lt_off = s_lt;
-            lt_n0 = s_lt + noff;
-            lt_pk = s_lt + noff + nint;
-            __syncthreads();
+    // ---- phases 2 and 1 -----------------------------------------------------------------------------
+    // Tables in LDS (g_lt, g_mr: file scope, see above) when both fit -- the fast form; otherwise the walk
+    // calls leaf_step_fly on the tables where they are, one search or two per step.
+    const uint32_t noff = 2 * (2 * T.S + 2) + 1;
+    const bool fast = sp.lt_off && sp.lt_merged && sp.rowz && sp.lt_words <= kLtLdsWords && sp.lt_merged_words <= kMergedLdsWords;
+    const uint32_t nint = fast ? (sp.lt_words - noff) / 2u : 0u;
+    if (fast) {
+        for (uint32_t i = threadIdx.x; i < noff; i += blockDim.x) g_lt[i] = sp.lt_off[i];
+        for (uint32_t i = threadIdx.x; i < nint; i += blockDim.x) {
+            g_lt[noff + i] = sp.lt_n0[i];
+            g_lt[noff + nint + i] = sp.lt_pk[i];
         }
+        for (uint32_t i = threadIdx.x; i < sp.lt_merged_words; i += blockDim.x) g_mr[i] = sp.lt_merged[i];
+        __syncthreads();
     }
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
-    for (uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x; gb < total; gb += gridDim.x * blockDim.x) {
+    const uint32_t SNB = T.S * T.NB1;
+    const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + T.NB1 - 1) / T.NB1);
+    if (sp.entry_phase == 2) {
+        // one lane per LEAF: which interval of its level's merged breakpoints the leaf's length falls into -- the
+        // only search a leaf needs, done for all of them at once instead of inside the sequential walk of phase 1
+        if (!fast) return;
+        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)total * LB; t += (uint64_t)gridDim.x * blockDim.x) {
+            const uint32_t gb = (uint32_t)(t / LB), l = (uint32_t)(t - (uint64_t)gb * LB);
+            uint32_t cap, lb;
+            locate_block(sp, gb, cap, lb);
+            uint64_t e0;
+            const uint64_t ne = cap_edges(sp.f, cap, e0);
+            const uint64_t first = 1 + (uint64_t)lb * LB;
+            const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+            if (l >= count) continue;
+            const uint64_t *edges = sp.f.edges + e0;
+            const uint64_t i = first + l;
+            const uint64_t n = edges[i] - edges[i - 1] - 1;
+            const uint32_t L = (uint32_t)(i & 1ull) ^ T.lvl0;
+            const uint32_t b0 = 4 + (L ? g_mr[0] : 0u);
+            uint32_t lo = 0, hi = g_mr[L];
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (g_mr[b0 + mid] <= (uint32_t)n) lo = mid;
+                else hi = mid;
+            }
+            sp.rowz[t] = n <= 0xfffffff0ull ? (uint16_t)lo : (uint16_t)0xffffu;
+        }
+        return;
+    }
+    // One lane in eight walks a block: a step that needs the full function (the first leaf after a skipped rest of
+    // a buffer, stuck codes: under one per cent of them, but whole blocks of them after a glitch) is paid by the
+    // whole wave; the walks are latency-bound chains, so more, emptier waves cost nothing.
+    if (fast && (threadIdx.x & 7u)) return;
+    const uint32_t per = fast ? 8u : 1u;
+    for (uint32_t gb = (blockIdx.x * blockDim.x + threadIdx.x) / per; gb < total; gb += (gridDim.x * blockDim.x) / per) {
         uint32_t cap, lb;
         locate_block(sp, gb, cap, lb);
         uint64_t e0;
@@ -1896,22 +1998,55 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const uint64_t *edges = sp.f.edges + e0;
-        const StuckCtx sc{edges, lt_off, lt_n0, lt_pk};
+        const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
         uint32_t s = sp.blk_in[gb];
-        // eight leaves at a time: their edges in one go (one memory latency per eight steps, not per step),
-        // their codes in one 16-byte store (block-major list: 2 * LB bytes per block, aligned)
+        // eight leaves at a time: their edges in one go (one memory latency per eight steps, not per step), their
+        // codes in one 16-byte store (block-major list: 2 * LB bytes per block, aligned).  Fast form: the eight row
+        // sets come from phase 2, a step is one read of the row the state selects plus its decode; a skip state
+        // whose buffer has not ended by the leaf's edge stays what it is; everything else takes the full step.
         uint4 *pre = reinterpret_cast<uint4 *>(sp.pre_codes + (size_t)gb * LB);
         uint64_t before = edges[first - 1];
         for (uint32_t l0 = 0; l0 < count; l0 += 8) {
             uint64_t ev[8];
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) ev[k] = edges[first + min(l0 + k, count - 1)];
+            uint32_t roff[8];
+            if (fast) {
+                const uint4 z4 = *reinterpret_cast<const uint4 *>(sp.rowz + (size_t)gb * LB + l0);
+                const uint32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                const uint32_t rows0 = 4 + g_mr[0] + g_mr[1], nbp0 = g_mr[0], twoS = 2u * T.S;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) {
+                    const uint32_t z = (zz[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
+                    const uint32_t L = (uint32_t)((first + l0 + k) & 1ull) ^ T.lvl0;
+                    roff[k] = z != 0xffffu ? rows0 + ((L ? nbp0 : 0u) + z) * twoS : 0xffffffffu;
+                }
+            }
             uint32_t code[8];
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) {
                 code[k] = s;
                 if (l0 + k < count) {
-                    s = leaf_step_fly(T, sc, first + l0 + k, before, ev[k], s);
+                    if (fast) {
+                        bool done = false;
+                        if (s < SNB && roff[k] != 0xffffffffu) {
+                            const uint32_t cur = __umulhi(s, rcpNB1), nb = s - cur * T.NB1;
+                            const uint32_t p = g_mr[roff[k] + 2u * cur + (nb >= T.max_bits ? 1u : 0u)];
+                            if (p & kPkAbsolute) {
+                                s = p & 0xffffu;
+                                done = true;
+                            } else if (p & kPkRelative) {
+                                const uint32_t nbo = nb + ((p >> 8) & 0xffffu);
+                                s = (p & 0xffu) * T.NB1 + (nbo >= T.NB1 ? T.NB1 - 1 : nbo);
+                                done = true;
+                            }
+                        } else if (s >= SNB && s < SNB + 2 && next_buffer_start(T, before) > ev[k]) {
+                            done = true;
+                        }
+                        if (!done) s = leaf_step_fly_g(T, sc, noff, nint, first + l0 + k, before, ev[k], s);
+                    } else {
+                        s = leaf_step_fly(T, sc, first + l0 + k, before, ev[k], s);
+                    }
                     before = ev[k];
                 }
             }
@@ -2717,6 +2852,43 @@ uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB) {
     return lb;
 }
 
+std::vector<uint32_t> build_merged_rows(uint32_t S, const std::vector<uint32_t> &off, const std::vector<uint32_t> &n0,
+                                        const std::vector<uint32_t> &pk) {
+    auto lookup = [&](uint32_t row, uint32_t L, uint32_t n) -> uint32_t {      // lt_lookup
+        uint32_t lo = off[2 * row + L], hi = off[2 * row + L + 1];
+        if (lo >= hi) return 0u;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (n0[mid] <= n) lo = mid;
+            else hi = mid;
+        }
+        return pk[lo];
+    };
+    std::vector<uint32_t> bp[2];
+    for (uint32_t L = 0; L < 2; ++L) {
+        bp[L].push_back(0);
+        for (uint32_t r = 0; r < 2 * S; ++r)
+            for (uint32_t i = off[2 * r + L]; i < off[2 * r + L + 1]; ++i) bp[L].push_back(n0[i]);
+        std::sort(bp[L].begin(), bp[L].end());
+        bp[L].erase(std::unique(bp[L].begin(), bp[L].end()), bp[L].end());
+    }
+    std::vector<uint32_t> out = {(uint32_t)bp[0].size(), (uint32_t)bp[1].size(), 2 * S, 0u};
+    out.insert(out.end(), bp[0].begin(), bp[0].end());
+    out.insert(out.end(), bp[1].begin(), bp[1].end());
+    for (uint32_t L = 0; L < 2; ++L) {
+        for (uint32_t n : bp[L]) {
+            for (uint32_t k = 0; k < S; ++k) {
+                // (what the leaf kernels make of a leaf's two lookups: a shared class-0 result also stands for class 1)
+                const uint32_t p0 = lookup(2 * k, L, n);
+                const uint32_t p1 = (p0 & kPkShared) ? p0 : lookup(2 * k + 1, L, n);
+                out.push_back(p0 & ~kPkShared);
+                out.push_back(p1 & ~kPkShared);
+            }
+        }
+    }
+    return out;
+}
+
 uint32_t fsm_scan_fin_block() { return (uint32_t)kFinBlock; }
 
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end) {
@@ -2758,6 +2930,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.nreach_base = a.first ? 0 : a.nreach_base;
     sp.nreach_lv[0] = a.nreach_lv[0];
     sp.nreach_lv[1] = a.nreach_lv[1];
+    sp.lt_words = a.lt_words;
+    sp.lt_merged = a.lt_merged;
+    sp.lt_merged_words = a.lt_merged_words;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.D = a.D;
     sp.cap_group_off = a.cap_group_off;
@@ -2841,10 +3016,15 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables
     sp.pre_codes = a.pre_codes;
     sp.blk_in = a.blk_in;
+    sp.rowz = a.rowz;
     sp.entry_phase = 0;
     hipLaunchKernelGGL(scan_entry_kernel, dim3(64), dim3(256), 0, stream, sp);
+    if (a.lt_off && a.lt_merged && a.rowz) {
+        sp.entry_phase = 2;
+        hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
+    }
     sp.entry_phase = 1;
-    hipLaunchKernelGGL(scan_entry_kernel, dim3(256), dim3(64), 0, stream, sp);
+    hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(emit_blocks), dim3(kSimThreads), 0, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);

@@ -291,6 +291,9 @@ struct FsmScanArgs {
     uint32_t grid_blocks;       // persistent workgroups for the leaf / emit kernels
     uint16_t *block_tab;        // [total_blocks_cap][D rounded up to 8]
     const uint32_t *lt_off, *lt_n0, *lt_pk;     // span tables from build_leaf_tables, or null
+    uint32_t lt_words;          // their size in words (offsets + 2 x intervals)
+    const uint32_t *lt_merged;  // build_merged_rows of them, or null
+    uint32_t lt_merged_words;
     const void *ltab;           // device copy of the kernels' table layout (fsm_scan_fill_ltab)
     PublishParams publish;      // d_hdr != null: the scan's last kernel also publishes the results
     const uint16_t *reach;      // codes a span can be entered in (ascending), or null = all
@@ -312,6 +315,7 @@ struct FsmScanArgs {
     uint32_t *cap_fallback;     // [captures] per-capture refusal bits (zero at launch), or null
     uint16_t *pre_codes;        // [total_blocks_cap][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [total_blocks_cap] entry code of every block
+    uint16_t *rowz;             // [total_blocks_cap][leaf_block] scratch of the entry passes: merged-rows interval of every leaf
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]
@@ -341,6 +345,13 @@ uint32_t fsm_scan_fill_ltab(void *dst, const FsmTablesDev &tables, uint32_t spb,
 bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim, std::vector<uint32_t> &off,
                        std::vector<uint32_t> &n0, std::vector<uint32_t> &pk, std::vector<uint16_t> &reach,
                        std::vector<uint16_t> &stuck_src, std::vector<uint8_t> &stuck_rows);
+// The span tables merged over the rows: per level the sorted union of all (state, class) rows' breakpoints,
+// and for every interval between two of them the 2S packed rows a span of that length has -- ONE search per
+// leaf, independent of the state the leaf is entered in.  Layout (32-bit words):
+//   [0] nbp level 0, [1] nbp level 1, [2] 2S, [3] 0 | bp level 0 | bp level 1 | rows level 0 [nbp0][2S] |
+//   rows level 1 [nbp1][2S]
+std::vector<uint32_t> build_merged_rows(uint32_t S, const std::vector<uint32_t> &off, const std::vector<uint32_t> &n0,
+                                        const std::vector<uint32_t> &pk);
 uint32_t fsm_scan_fin_block();
 // t_end (optional): event that takes the end time stamp of the scan's last kernel
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end = nullptr);

@@ -299,6 +299,7 @@ struct ookd_rx {
     uint32_t front_launches = 1;    // of the last run
     DevBuf<uint32_t> d_cap_fallback;        // [captures] the scan's per-capture refusal bits (batched runs)
     DevBuf<uint16_t> d_pre, d_blk_in;       // entry code of every leaf / block (scan_entry_kernel)
+    DevBuf<uint16_t> d_rowz;                // merged-rows interval of every leaf (scan_entry_kernel)
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
@@ -345,6 +346,7 @@ struct ookd_rx {
     uint32_t scan_max_bits = 0;
     DevBuf<uint16_t> d_block_tab;
     DevBuf<uint32_t> d_lt_off, d_lt_n0, d_lt_pk;    // span tables (empty = the scan simulates)
+    DevBuf<uint32_t> d_lt_merged;                    // build_merged_rows of them
     DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
     DevBuf<uint16_t> d_reach;       // abstract codes a span can be entered in (empty = all)
     DevBuf<uint32_t> d_cap_group_off;
@@ -395,6 +397,7 @@ struct ookd_rx {
         d_cap_fallback.release();
         d_pre.release();
         d_blk_in.release();
+        d_rowz.release();
         d_chunk_totals.release();
         d_fin_tickets.release();
         for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
@@ -421,6 +424,7 @@ struct ookd_rx {
         d_lt_off.release();
         d_lt_n0.release();
         d_lt_pk.release();
+        d_lt_merged.release();
         d_ltab.release();
         d_reach.release();
         d_cap_group_off.release();
@@ -743,6 +747,9 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.lt_off = d_lt_off.p;
         a.lt_n0 = d_lt_n0.p;
         a.lt_pk = d_lt_pk.p;
+        a.lt_words = (uint32_t)(d_lt_off.n + d_lt_n0.n + d_lt_pk.n);
+        a.lt_merged = d_lt_merged.p;
+        a.lt_merged_words = (uint32_t)d_lt_merged.n;
         a.ltab = d_ltab.p;
         a.reach = d_reach.p;
         a.nreach = scan_reach_n;
@@ -779,6 +786,7 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.edge_overflow = &d_hdr.p->edge_overflow;
         a.pre_codes = d_pre.p;
         a.blk_in = d_blk_in.p;
+        a.rowz = d_rowz.p;
         a.final_state = d_carry.p + (c & 1);
         a.fallback = &d_hdr.p->scan_fallback;
         a.fin_off = d_fin_off.p;
@@ -1052,6 +1060,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_off = d_lt_off.p;
     a.lt_n0 = d_lt_n0.p;
     a.lt_pk = d_lt_pk.p;
+    a.lt_words = (uint32_t)(d_lt_off.n + d_lt_n0.n + d_lt_pk.n);
+    a.lt_merged = d_lt_merged.p;
+    a.lt_merged_words = (uint32_t)d_lt_merged.n;
     a.ltab = d_ltab.p;
     a.reach = d_reach.p;
     a.nreach = scan_reach_n;
@@ -1081,6 +1092,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.edge_overflow = &d_hdr.p->edge_overflow;
     a.pre_codes = d_pre.p;
     a.blk_in = d_blk_in.p;
+    a.rowz = d_rowz.p;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = &d_hdr.p->fin_ticket;
@@ -1542,6 +1554,11 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                      hipMemcpy(rx->d_lt_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
                     rc = OOKD_ERR_HIP;
                 }
+                const std::vector<uint32_t> merged = build_merged_rows(rx->scan_S, off, n0, pk);
+                rc |= rx->d_lt_merged.alloc(merged.size());
+                if (rc == OOKD_OK && hipMemcpy(rx->d_lt_merged.p, merged.data(), merged.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                    rc = OOKD_ERR_HIP;
+                }
             }
         }
         if (rx->scan_ok) {
@@ -1569,6 +1586,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
             rc |= rx->d_pre.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
+            rc |= rx->d_rowz.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
