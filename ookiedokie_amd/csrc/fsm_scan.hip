@@ -514,6 +514,7 @@ struct ScanParams {
     const uint32_t *lt_merged;          // build_merged_rows of the span tables, or null
     uint32_t lt_merged_words;
     uint32_t Dp, D;             // block table row pitch (D rounded up to 8); D = the domain with the stuck codes
+    uint32_t S;                 // machine states
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
     uint16_t *group_in;         // [groups]
@@ -1558,34 +1559,46 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
     __shared__ uint64_t s_resume[64];
     __shared__ uint32_t s_cap[kCapWords];
     __shared__ uint32_t s_lt[kLtLdsWords];
-    copy_ltab(T, sp.ltab);
-    wave_sync_lds();
-    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
-    wave_sync_lds();
-    if (*sp.fallback) return;
+    // Start-up in ONE round trip to memory: a workgroup handles one or two blocks (the grid is several times what
+    // the chip holds -- the hardware hands workgroups out as others finish, which is what evens out the blocks
+    // behind a glitch), so what it does before its first block counts.  Every word of the table image, the span
+    // tables (their size comes with the launch: the launcher picks this kernel only when they fit the LDS) and
+    // the fallback word is requested before any of them is waited for.
     const uint32_t lane = threadIdx.x;
+    const uint32_t noff = 2 * (2 * sp.S + 2) + 1, nint = (sp.lt_words - noff) / 2u;
+    {
+        constexpr uint32_t kT4 = (uint32_t)(sizeof(LTab) / 16), kTper = (kT4 + 63u) / 64u, kLper = (kLtLdsWords + 63u) / 64u;
+        const uint4 *tsrc = static_cast<const uint4 *>(sp.ltab);
+        uint4 tv[kTper];
+        uint32_t lv[kLper];
+#pragma unroll
+        for (uint32_t r = 0; r < kTper; ++r) tv[r] = lane + 64u * r < kT4 ? tsrc[lane + 64u * r] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t r = 0; r < kLper; ++r) {
+            const uint32_t i = lane + 64u * r;
+            lv[r] = i < noff ? sp.lt_off[i] : (i < noff + nint ? sp.lt_n0[i - noff] : (i < noff + 2u * nint ? sp.lt_pk[i - noff - nint] : 0u));
+        }
+        const uint32_t fb = *sp.fallback;
+        const uint32_t lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
+        uint4 *tdst = reinterpret_cast<uint4 *>(&T);
+#pragma unroll
+        for (uint32_t r = 0; r < kTper; ++r)
+            if (lane + 64u * r < kT4) tdst[lane + 64u * r] = tv[r];
+#pragma unroll
+        for (uint32_t r = 0; r < kLper; ++r)
+            if (lane + 64u * r < noff + 2u * nint) s_lt[lane + 64u * r] = lv[r];
+        wave_sync_lds();
+        if (lane == 0) T.lvl0 = lvl0;
+        wave_sync_lds();
+        if (fb) return;
+    }
     const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, D = T.D, nsim = 2 * S + 4, max_bits = T.max_bits;
     const uint32_t D0 = SNB + 3;
     const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + NB1 - 1) / NB1);
     WaveLds b;
     b.res = reinterpret_cast<uint32_t *>(scan_smem);
     b.ctab = reinterpret_cast<uint16_t *>(scan_smem + (size_t)64 * nsim * 4);
-    // the span tables are searched from LDS when they fit (the shipped devices: 409 words)
-    const uint32_t *lt_off = sp.lt_off, *lt_n0 = sp.lt_n0, *lt_pk = sp.lt_pk;
-    {
-        const uint32_t noff = 2 * (2 * S + 2) + 1, nint = lt_off[noff - 1];
-        if (noff + 2 * nint <= kLtLdsWords) {
-            for (uint32_t i = lane; i < noff; i += 64) s_lt[i] = sp.lt_off[i];
-            for (uint32_t i = lane; i < nint; i += 64) {
-                s_lt[noff + i] = sp.lt_n0[i];
-                s_lt[noff + nint + i] = sp.lt_pk[i];
-            }
-            lt_off = s_lt;
-            lt_n0 = s_lt + noff;
-            lt_pk = s_lt + noff + nint;
-            wave_sync_lds();
-        }
-    }
+    const uint32_t *const lt_off = s_lt, *const lt_n0 = s_lt + noff, *const lt_pk = s_lt + noff + nint;
     const uint32_t LB = sp.leaf_block;          // 64
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     for (uint32_t gb = blockIdx.x; gb < total + sp.f.num_captures; gb += gridDim.x) {
@@ -2935,6 +2948,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.lt_merged_words = a.lt_merged_words;
     sp.Dp = (a.D + 7u) & ~7u;
     sp.D = a.D;
+    sp.S = a.S;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;
     sp.group_in = a.group_in;
@@ -2953,7 +2967,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     // workgroup-per-block form, which is also what runs without span tables)
     const char *const leaf_env = getenv("OOKD_SCAN_LEAF");       // (looked up per launch: the tests switch it)
     const size_t lds_wave = wave_lds_bytes(a.D, a.S);
-    const bool wave_form = a.lt_off && a.leaf_block == 64 && lds_wave <= 60u * 1024u && !(leaf_env && leaf_env[0] == 'b');
+    const bool wave_form = a.lt_off && a.lt_words && a.lt_words <= kLtLdsWords && a.leaf_block == 64 && lds_wave <= 60u * 1024u &&
+                           !(leaf_env && leaf_env[0] == 'b');
     if (wave_form) {
         e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_leaf_wave_kernel), lds_wave);
         if (e != hipSuccess) return e;
@@ -2973,7 +2988,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
             hipDeviceProp_t prop;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_leaf_wave_kernel, 64, lds_wave) == hipSuccess &&
                 hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 && per_cu > 0) {
-                wave_grid = (uint32_t)(per_cu * prop.multiProcessorCount);
+                // four times what the chip holds at once: the hardware's hand-out of workgroups balances the blocks
+                wave_grid = 4u * (uint32_t)(per_cu * prop.multiProcessorCount);
             } else {
                 (void)hipGetLastError();
                 wave_grid = 4 * a.grid_blocks;
