@@ -270,7 +270,8 @@ struct ookd_rx {
     int quiet_lsb = 0;              // 0 = the quiet shortcut never applies
     bool exact = false;
     bool count_quiet = false;
-    DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics)
+    DevBuf<uint32_t> d_quiet;       // kQuietCounters spread counters (diagnostics), running totals
+    std::vector<uint32_t> quiet_prev;       // what they held after the run before
     DevBuf<uint32_t> d_tile_info;   // per wave tile edge counts written by the tuned front-end kernels
     DevBuf<uint32_t> d_ctl;         // streaming front end: ticket heads | chunk counters | chunk ends
     // sparse front-end output: quiet tiles store nothing; the tile infos carry the run's stamp and tiles
@@ -678,7 +679,6 @@ int ookd_rx::run_pipelined(const void *d_iq) {
     }
     if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
     hdr_dirty = true;
-    if (count_quiet) HIPCHK(hipMemsetAsync(d_quiet.p, 0, sizeof(uint32_t) * kQuietCounters, stream));
     HIPCHK(hipMemsetAsync(d_fin_tickets.p, 0, sizeof(uint32_t) * nc, stream));
     FrontParams fp = front_params(d_iq, run_n_valid);
     {
@@ -807,7 +807,6 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
                              uint32_t halo_len) {
     if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
     hdr_dirty = true;
-    if (count_quiet) HIPCHK(hipMemsetAsync(d_quiet.p, 0, sizeof(uint32_t) * kQuietCounters, stream));
     FrontParams fp = front_params(d_iq, stride);
     fp.halo = d_halo_ptr;
     fp.halo_len = halo_len;
@@ -1235,9 +1234,16 @@ int ookd_rx::collect_results() {
     stats.total_waves = front_wave_tiles(front_params(nullptr, 0)) * run_caps;
     if (stats.total_waves) {
         if (count_quiet) {
+            // running counters (never zeroed: a memset per run is a 20 us fill kernel on the critical path):
+            // this run's share is the difference to what the run before left, modulo 2^32 per counter
             std::vector<uint32_t> q(kQuietCounters);
-            HIPCHK(hipMemcpy(q.data(), d_quiet.p, q.size() * 4, hipMemcpyDeviceToHost));
-            for (uint32_t v : q) stats.quiet_waves += v;
+            HIPCHK(hipMemcpyAsync(q.data(), d_quiet.p, q.size() * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (quiet_prev.size() != q.size()) quiet_prev.assign(q.size(), 0u);
+            for (size_t i = 0; i < q.size(); ++i) {
+                stats.quiet_waves += (uint32_t)(q[i] - quiet_prev[i]);
+                quiet_prev[i] = q[i];
+            }
         }
     }
     stats.input_samples = run_n_in;
@@ -1478,6 +1484,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rc |= rx->d_hdr.alloc(1);
     rx->count_quiet = (cfg->flags & OOKD_RX_COUNT_QUIET) != 0;
     if (rx->count_quiet) rc |= rx->d_quiet.alloc(kQuietCounters);
+    if (rx->count_quiet && rc == OOKD_OK && hipMemset(rx->d_quiet.p, 0, kQuietCounters * sizeof(uint32_t)) != hipSuccess) rc = OOKD_ERR_HIP;
     if (rx->have_fsm) {
         rc |= rx->d_seg_bounds.alloc(caps * (rx->max_segs_per_cap + 1));
         rc |= rx->d_state_in.alloc(nseg);
