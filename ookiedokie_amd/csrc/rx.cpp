@@ -1812,7 +1812,47 @@ int ookd_scan_domain_info(const ookd_device *device, uint32_t samples_per_buffer
     size_t zeros = 0;
     for (uint32_t v : pk) zeros += v == 0;
     const uint32_t S = (uint32_t)device->state_duration_us.size();
-    out[0] = ok ? 1u : 0u;
+    // the merged rows (one search per leaf for scan_entry_kernel) must say what the per-row searches say, at
+    // every breakpoint, next to it and far beyond: a mismatch reports the tables as not built
+    bool merged_ok = true;
+    if (ok && !n0.empty()) {
+        const std::vector<uint32_t> m = build_merged_rows(S, off, n0, pk);
+        auto lookup = [&](uint32_t row, uint32_t L, uint32_t n) -> uint32_t {
+            uint32_t lo = off[2 * row + L], hi = off[2 * row + L + 1];
+            if (lo >= hi) return 0u;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (n0[mid] <= n) lo = mid;
+                else hi = mid;
+            }
+            return pk[lo];
+        };
+        std::vector<uint32_t> probes = {0u, 1u, 0xfffffff0u, 0x7fffffffu};
+        for (uint32_t v : n0) {
+            probes.push_back(v);
+            probes.push_back(v + 1);
+            if (v) probes.push_back(v - 1);
+        }
+        for (uint32_t L = 0; L < 2 && merged_ok; ++L) {
+            const uint32_t nbp = m[L];
+            const uint32_t *bp = m.data() + 4 + (L ? m[0] : 0u);
+            for (uint32_t n : probes) {
+                uint32_t lo = 0, hi = nbp;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (bp[mid] <= n) lo = mid;
+                    else hi = mid;
+                }
+                const uint32_t *rows = m.data() + 4 + m[0] + m[1] + ((L ? m[0] : 0u) + lo) * 2u * S;
+                for (uint32_t k = 0; k < S; ++k) {
+                    const uint32_t p0 = lookup(2 * k, L, n);
+                    const uint32_t p1 = (p0 & 0x10000000u) ? p0 : lookup(2 * k + 1, L, n);      // kPkShared
+                    if (rows[2 * k] != (p0 & ~0x10000000u) || rows[2 * k + 1] != (p1 & ~0x10000000u)) merged_ok = false;
+                }
+            }
+        }
+    }
+    out[0] = (ok && merged_ok) ? 1u : 0u;
     out[1] = (uint32_t)n0.size();
     out[2] = (uint32_t)zeros;
     out[3] = (uint32_t)reach.size();

@@ -207,7 +207,9 @@ def test_synth_tx_walk_matches_reference_sm_generate(oracle):
 @pytest.mark.parametrize("name,stuck", [("p3l-nexa2012", 36), ("unknown-remote1", 32)])
 @pytest.mark.parametrize("rate", [3000000, 750000])
 def test_scan_domain_of_the_shipped_devices(name, stuck, rate):
-    """Host logic of the scan form (no GPU): span tables build, every interval is a
+    """Host logic of the scan form (no GPU): span tables build (and their merged form -- one search per
+    leaf -- says at every breakpoint, next to it and far beyond what the per-row searches say: a
+    mismatch reports `built` = 0), every interval is a
     looked-up result, the level-aware closure finds the codes a glitch inside a bit gap
     leaves "stuck" (bit_off_time with fewer than max_bits bits, one table row), and the
     domain with their twins stays within 512 codes."""
