@@ -1053,3 +1053,29 @@ def test_fresh_contexts_and_shards_repeat_exactly(ok, oracle, vectors, filt, lea
         assert got == want_msgs, (it, "sharded", r0.stats["fsm_path"], r1.stats["fsm_path"])
         rx0.close()
         rx1.close()
+
+
+@pytest.mark.parametrize("short_by", [1, 9, 100])
+def test_edge_list_overflow_with_a_state_machine_is_refused_cleanly(ok, oracle, vectors, short_by):
+    """An edge list a few entries too small for the capture (round-1 advisor finding: the scan form sized its
+    buffers by the capacity and never looked at the overflow flag): the call must fail with the capacity
+    error -- not decode something, not touch what lies behind its buffers -- and a context made and run right
+    after it, whose buffers are likely to be the neighbours in device memory, must still decode the capture
+    exactly."""
+    g, iq = _g1(vectors, noise_seed=41)
+    n = iq.size // 2
+    f = _flt(ok, "fs32_fs4")
+    d = _dev(ok, "p3l-nexa2012")
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, _odev(oracle, "p3l-nexa2012"), 8192, want_bits=True)
+    nedges = len(edges_of(want.bits))
+    assert nedges > 200
+    small = ok.Receiver(f, d, max_samples=n, edge_capacity=nedges - short_by)
+    good = ok.Receiver(f, d, max_samples=n)
+    for _ in range(3):
+        with pytest.raises(ok.OokdError):
+            small.rx(iq)
+        got = good.rx(iq)
+        assert list(got.msg_samples) == list(want.msg_samples) and (got.payloads == want.payloads).all()
+        assert list(good.edges()) == list(edges_of(want.bits))
+    small.close()
+    good.close()
