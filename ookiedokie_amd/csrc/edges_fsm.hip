@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
 // their words read (8 or 16 words) -- a capture is mostly constant level, so that is a few
 // percent of the bit words, where edge_write_kernel reads every word of every block that
 // holds an edge.  Positions come out ascending: tiles in order, words in order, bits in order.
+template <uint32_t TPB>
 __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams p) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,36 +243,59 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
     p.blk_offset[b] = off;
     if (p.blk_count[b] == 0) return;
     const uint32_t cap = b / p.blocks_per_cap, blk = b - cap * p.blocks_per_cap;
-    const uint32_t tpb = p.tiles_per_block;
-    const uint32_t words_per_tile = (uint32_t)kBlockWords / tpb;
-    const uint32_t tile_bits = words_per_tile * 64u;
+    constexpr uint32_t tpb = TPB;           // wave tiles per 4096-bit block: 4, 8 or 16 (compile time: everything unrolls)
+    constexpr uint32_t words_per_tile = (uint32_t)kBlockWords / tpb;
+    constexpr uint32_t tile_bits = words_per_tile * 64u;
     const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     const uint32_t t0 = blk * tpb;
-    uint32_t prev_last = (t0 || p.has_prev) ? tile_live(*(ti + t0 - 1), p.stamp_bits) >> 31 : 0u;
-    uint64_t at = off;
-    for (uint32_t t = 0; t < tpb; ++t) {
-        const bool live = (uint64_t)(t0 + t) * tile_bits < p.n_out;
-        const uint32_t info = live ? tile_live(ti[t0 + t], p.stamp_bits) : 0u;
-        const uint32_t c = live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
-        if (c) {
-            const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
-            uint64_t carry = prev_last;
-            for (uint32_t i = 0; i < words_per_tile; ++i) {
-                const uint64_t cur = words[w0 + i];
-                uint64_t e = cur ^ ((cur << 1) | carry);
-                carry = cur >> 63;
-                const uint64_t base = (w0 + i) * 64;
-                if (base + 64 > p.n_out) e &= base >= p.n_out ? 0ull : ((1ull << (p.n_out - base)) - 1ull);
-                while (e) {
-                    const int bit = __ffsll((long long)e) - 1;
-                    if (at < p.edge_capacity) p.edges[at] = base + (uint64_t)bit;
-                    ++at;
-                    e &= e - 1;
+    // Few round trips to memory per lane (the kernel is latency times rounds of waves): the block's tile infos in
+    // one go (4, 8 or 16 dwords = 1, 2 or 4 16-byte loads), then every loud tile's words in one go (64 bytes).
+    uint32_t infos[tpb];
+    {
+        const uint32_t prev_info = (t0 || p.has_prev) ? *(ti + t0 - 1) : 0u;
+        const uint4 *ti4 = reinterpret_cast<const uint4 *>(ti + t0);
+#pragma unroll
+        for (uint32_t q = 0; q < tpb / 4; ++q) {
+            const uint4 v = ti4[q];
+            infos[4 * q + 0] = v.x;
+            infos[4 * q + 1] = v.y;
+            infos[4 * q + 2] = v.z;
+            infos[4 * q + 3] = v.w;
+        }
+        uint32_t prev_last = (t0 || p.has_prev) ? tile_live(prev_info, p.stamp_bits) >> 31 : 0u;
+        uint64_t at = off;
+#pragma unroll
+        for (uint32_t t = 0; t < tpb; ++t) {
+            const bool live = (uint64_t)(t0 + t) * tile_bits < p.n_out;
+            const uint32_t info = live ? tile_live(infos[t], p.stamp_bits) : 0u;
+            const uint32_t c = live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+            if (c) {
+                const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
+                // the tile's words (4, 8 or 16 of them), requested together
+                uint4 wv[words_per_tile / 2];
+                const uint4 *w4 = reinterpret_cast<const uint4 *>(words + w0);
+#pragma unroll
+                for (uint32_t q = 0; q < words_per_tile / 2; ++q) wv[q] = w4[q];
+                uint64_t carry = prev_last;
+#pragma unroll
+                for (uint32_t i = 0; i < words_per_tile; ++i) {
+                    const uint4 v = wv[i >> 1];
+                    const uint64_t cur = (i & 1u) ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
+                    uint64_t e = cur ^ ((cur << 1) | carry);
+                    carry = cur >> 63;
+                    const uint64_t base = (w0 + i) * 64;
+                    if (base + 64 > p.n_out) e &= base >= p.n_out ? 0ull : ((1ull << (p.n_out - base)) - 1ull);
+                    while (e) {
+                        const int bit = __ffsll((long long)e) - 1;
+                        if (at < p.edge_capacity) p.edges[at] = base + (uint64_t)bit;
+                        ++at;
+                        e &= e - 1;
+                    }
                 }
             }
+            prev_last = live ? info >> 31 : prev_last;
         }
-        prev_last = live ? info >> 31 : prev_last;
     }
 }
 
@@ -917,7 +941,11 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
     if (p.tile_info) {
-        hipLaunchKernelGGL(edge_write_tiles_kernel, dim3((total_blocks + 255) / 256), dim3(256), 0, stream, p);
+        const dim3 grid((total_blocks + 255) / 256);
+        if (p.tiles_per_block == 4) hipLaunchKernelGGL(edge_write_tiles_kernel<4>, grid, dim3(256), 0, stream, p);
+        else if (p.tiles_per_block == 8) hipLaunchKernelGGL(edge_write_tiles_kernel<8>, grid, dim3(256), 0, stream, p);
+        else if (p.tiles_per_block == 16) hipLaunchKernelGGL(edge_write_tiles_kernel<16>, grid, dim3(256), 0, stream, p);
+        else return hipErrorInvalidValue;
     } else {
         const uint32_t write_waves = (total_blocks + kWriteSpan - 1) / kWriteSpan;
         hipLaunchKernelGGL(edge_write_kernel, dim3((write_waves + 3) / 4), dim3(256), 0, stream, p);
