@@ -650,17 +650,6 @@ __device__ __noinline__ uint32_t stuck_step(const LTab &T, const StuckCtx &c, ui
     return code_poison(T);              // deeper, position dependent or bit-count sensitive: not followed
 }
 
-// the span of leaf i as the simulator has to run it when the leaf is entered in `code`
-__device__ __forceinline__ Span span_entered(const LTab &T, const uint64_t *edges, uint64_t i, uint32_t &code) {
-    Span sp = span_of(T, edges, i);
-    if (code >= T.S * T.NB1 + 3) {
-        uint32_t d, src;
-        stuck_decode(T, code, d, src);
-        sp.prefix = edges[i - 1] - edges[i - d - 1];
-        code = src;
-    }
-    return sp;
-}
 
 constexpr uint32_t kCapWords = (256 + kStuckDepth + 31) / 32;
 constexpr uint32_t kLtLdsWords = 768;   // span tables up to this size are searched from LDS (shipped devices: 409)
@@ -2073,8 +2062,6 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
 __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
-    __shared__ uint64_t s_resume[256];
-    __shared__ uint16_t pre[257];
     copy_ltab(T, sp.ltab);
     __syncthreads();
     if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
@@ -2093,18 +2080,16 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             LeafEvDev *events = sp.events + e0 + cap;
             const uint64_t first = 1 + (uint64_t)lb * LB;
             const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
-            // the leaves' entry codes are there already (scan_entry_kernel): no table is staged
-            for (uint32_t l = threadIdx.x; l < count; l += blockDim.x) {
-                s_resume[l] = next_buffer_start(T, edges[first + l - 1]);
-                pre[l] = sp.pre_codes[(size_t)w * LB + l];
-            }
-            __syncthreads();
-            // a wavefront takes the leaves entered in "its" states (state mod 16; skip
-            // and poison codes form row S), so its lanes run the same triggers
+            // The leaves' entry codes are there already (scan_entry_kernel): no table is staged, nothing goes through
+            // the LDS, no barrier -- every lane asks for its leaf's code and its two edges at once (one round trip to
+            // memory per block; the four waves ask for the same 64 leaves, which the cache absorbs), then a wavefront
+            // takes the leaves entered in "its" states (state mod 4; skip and poison codes form row S), so that its
+            // lanes run the same triggers.
             const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
             for (uint32_t l = threadIdx.x & 63u; l < count; l += 64) {
                 const uint64_t i = first + l;
-                uint32_t in = pre[l];
+                uint32_t in = sp.pre_codes[(size_t)w * LB + l];
+                const uint64_t e_before = edges[i - 1], e_at = edges[i];
                 if ((in / T.NB1) % nwaves != wave) continue;
                 PSim f;
                 Acc a;
@@ -2114,13 +2099,23 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     acc_init(a);
                     f.cur = f.nbits = f.k = f.prev = 0;
                 } else {
-                    const Span span = span_entered(T, edges, i, in);       // stuck: from where it was normal
-                    alive = run_leaf(T, in, span, s_resume[l], f, a);
+                    Span span;
+                    span.pos0 = e_before + 1;
+                    span.n = e_at - e_before - 1;
+                    span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
+                    span.has_edge = true;
+                    span.prefix = 0;
+                    if (in >= T.S * T.NB1 + 3) {            // entered stuck: from where the state was normal (span_entered)
+                        uint32_t d, src;
+                        stuck_decode(T, in, d, src);
+                        span.prefix = e_before - edges[i - d - 1];
+                        in = src;
+                    }
+                    alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
                     if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                 }
                 write_event(events[i], a, f, alive);
             }
-            __syncthreads();
         } else {
             const uint32_t cap = w - total;
             uint64_t e0;
