@@ -490,6 +490,8 @@ struct ScanParams {
     uint16_t *pre_codes;        // [blocks][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [blocks] entry code of every block
     uint16_t *rowz;             // [blocks][leaf_block] merged-rows interval of every leaf (0xffff: span too long for the tables)
+    uint32_t *skipc;            // [blocks][leaf_block] the leaf applied to the two skip codes: out(skip 0) | out(skip 1) << 16
+    uint32_t skipc_valid;       // the leaf kernel of this launch fills skipc (wave-per-block form)
     uint32_t entry_phase;       // scan_entry_kernel: 0 groups -> blocks, 1 blocks -> chunks -> leaves
     uint32_t *cap_fallback;     // [captures] refusal bits per capture (batched runs; zero at launch), or null: a
                                 // capture whose path leaves the model is left out of the results -- the host
@@ -1649,6 +1651,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
             // row (reset, few bits) of a shorter span when the level before the skip equals the span's, a
             // special row otherwise.
             const uint64_t end_const = span.pos0 + span.n, last = end_const + 1;
+            uint32_t skip_pair = 0;
             for (uint32_t kk = 0; kk < 2; ++kk) {
                 uint32_t out;
                 if (rs >= last) {
@@ -1670,8 +1673,12 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
                     }
                 }
                 row[2 * S + kk] = pack_absolute(out, NB1);
+                skip_pair |= out << (16u * kk);
             }
             row[2 * S + 2] = row[2 * S + 3] = pack_absolute(SNB + 2, NB1);
+            // (kept for the entry walk: a leaf entered skipping is the one case it would otherwise have to redo --
+            //  a lookup at the remaining length or a simulation; 4 bytes per leaf, one coalesced store per block)
+            if (sp.skipc) sp.skipc[(size_t)gb * LB + l] = skip_pair;
         } else if (lane < nch * kChunk) {
             // padding of a short last chunk: identity rows (the fast walk always takes 16 steps)
             uint32_t *row = b.res + lane * nsim;
@@ -2012,9 +2019,15 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
             uint64_t ev[8];
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) ev[k] = edges[first + min(l0 + k, count - 1)];
-            uint32_t roff[8];
+            uint32_t roff[8], skp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (fast) {
                 const uint4 z4 = *reinterpret_cast<const uint4 *>(sp.rowz + (size_t)gb * LB + l0);
+                if (sp.skipc_valid) {
+                    const uint4 *sk4 = reinterpret_cast<const uint4 *>(sp.skipc + (size_t)gb * LB + l0);
+                    const uint4 s0 = sk4[0], s1 = sk4[1];
+                    skp[0] = s0.x; skp[1] = s0.y; skp[2] = s0.z; skp[3] = s0.w;
+                    skp[4] = s1.x; skp[5] = s1.y; skp[6] = s1.z; skp[7] = s1.w;
+                }
                 const uint32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
                 const uint32_t rows0 = 4 + g_mr[0] + g_mr[1], nbp0 = g_mr[0], twoS = 2u * T.S;
 #pragma unroll
@@ -2042,8 +2055,14 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
                                 s = (p & 0xffu) * T.NB1 + (nbo >= T.NB1 ? T.NB1 - 1 : nbo);
                                 done = true;
                             }
-                        } else if (s >= SNB && s < SNB + 2 && next_buffer_start(T, before) > ev[k]) {
-                            done = true;
+                        } else if (s >= SNB && s < SNB + 2) {
+                            if (sp.skipc_valid) {
+                                const uint32_t stored = (skp[k] >> (16u * (s - SNB))) & 0xffffu;
+                                s = stored;     // what the leaf kernel found for this leaf
+                                done = true;
+                            } else if (next_buffer_start(T, before) > ev[k]) {
+                                done = true;                                    // still skipping when the span ends
+                            }
                         }
                         if (!done) s = leaf_step_fly_g(T, sc, noff, nint, first + l0 + k, before, ev[k], s);
                     } else {
@@ -3017,6 +3036,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     const uint32_t leaf_blocks = grid_env ? (uint32_t)atoi(grid_env) : leaf_grid;
     const uint32_t emit_blocks = grid_env ? (uint32_t)atoi(grid_env) : emit_grid;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
+    // (before the leaf kernel's launch: it is the one that fills the list)
+    sp.skipc = wave_form ? a.skipc : nullptr;
+    sp.skipc_valid = sp.skipc ? 1u : 0u;
     if (wave_form) {
         hipLaunchKernelGGL(scan_leaf_wave_kernel, dim3(grid_env ? (uint32_t)atoi(grid_env) : wave_grid), dim3(64), lds_wave, stream, sp);
     } else {

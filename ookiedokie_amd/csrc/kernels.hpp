@@ -316,6 +316,7 @@ struct FsmScanArgs {
     uint16_t *pre_codes;        // [total_blocks_cap][leaf_block] entry code of every leaf (scan_entry_kernel)
     uint16_t *blk_in;           // [total_blocks_cap] entry code of every block
     uint16_t *rowz;             // [total_blocks_cap][leaf_block] scratch of the entry passes: merged-rows interval of every leaf
+    uint32_t *skipc;            // [total_blocks_cap][leaf_block] every leaf applied to the two skip codes (wave leaf kernel -> entry walk)
     SegState *final_state;      // [captures]
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]

@@ -301,6 +301,7 @@ struct ookd_rx {
     DevBuf<uint32_t> d_cap_fallback;        // [captures] the scan's per-capture refusal bits (batched runs)
     DevBuf<uint16_t> d_pre, d_blk_in;       // entry code of every leaf / block (scan_entry_kernel)
     DevBuf<uint16_t> d_rowz;                // merged-rows interval of every leaf (scan_entry_kernel)
+    DevBuf<uint32_t> d_skipc;               // every leaf applied to the two skip codes (leaf kernel -> entry walk)
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
@@ -399,6 +400,7 @@ struct ookd_rx {
         d_pre.release();
         d_blk_in.release();
         d_rowz.release();
+        d_skipc.release();
         d_chunk_totals.release();
         d_fin_tickets.release();
         for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
@@ -787,6 +789,7 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.pre_codes = d_pre.p;
         a.blk_in = d_blk_in.p;
         a.rowz = d_rowz.p;
+        a.skipc = d_skipc.p;
         a.final_state = d_carry.p + (c & 1);
         a.fallback = &d_hdr.p->scan_fallback;
         a.fin_off = d_fin_off.p;
@@ -1092,6 +1095,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.pre_codes = d_pre.p;
     a.blk_in = d_blk_in.p;
     a.rowz = d_rowz.p;
+    a.skipc = d_skipc.p;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = &d_hdr.p->fin_ticket;
@@ -1594,6 +1598,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_cap_fallback.alloc(caps);
             rc |= rx->d_pre.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_rowz.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
+            rc |= rx->d_skipc.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
