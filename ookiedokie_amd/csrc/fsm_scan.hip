@@ -1439,7 +1439,7 @@ __host__ __device__ __forceinline__ size_t wave_lds_bytes(uint32_t D, uint32_t S
 }
 
 // one step of the slow path: everything leaf_step_fly knows, from the block's packed rows
-__device__ __noinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
+__device__ __forceinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
                                                 uint32_t l, const uint32_t *res, const uint64_t *resume, uint32_t s) {
     const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1;
     const uint32_t *row = res + l * (2 * S + 4);
@@ -1459,6 +1459,14 @@ __device__ __noinline__ uint32_t wave_step_slow(const LTab &T, const StuckCtx &s
     Acc a;
     const bool alive = run_leaf(T, s, span_of(T, edges, first + l), resume[l], f, a);
     return encode_post(T, f, a, alive);
+}
+
+// A whole chain through the slow path, leaves la .. lb-1: ONE call (the kernel that calls it keeps ~190 registers
+// live; a call per step had it save and restore them sixteen times per chain).
+__device__ __noinline__ uint32_t wave_chain_slow(const LTab &T, const StuckCtx &sc, const uint64_t *edges, uint64_t first,
+                                                 uint32_t la, uint32_t lb, const uint32_t *res, const uint64_t *resume, uint32_t v) {
+    for (uint32_t l = la; l < lb; ++l) v = wave_step_slow(T, sc, edges, first, l, res, resume, v);
+    return v;
 }
 
 // K chains per lane, each through the 16 leaves of its chunk (a short last chunk is padded with identity rows).
@@ -1535,10 +1543,7 @@ __device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, 
         if (dst[j] == 0xffffffffu) continue;
         if ((trapped >> j) & 1u) {
             // met a row the fast walk does not know: again from the start, one full step at a time
-            uint32_t v = code[j];
-            const uint32_t lb = min(la[j] + (uint32_t)kChunk, count);
-            for (uint32_t l = la[j]; l < lb; ++l) v = wave_step_slow(T, sc, edges, first, l, b.res, resume, v);
-            st[j] = v;
+            st[j] = wave_chain_slow(T, sc, edges, first, la[j], min(la[j] + (uint32_t)kChunk, count), b.res, resume, code[j]);
         }
         b.ctab[dst[j]] = (uint16_t)st[j];
     }
@@ -1750,9 +1755,7 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
                     // STUCK_d enters the chunk only if the leaf d before it can end stuck
                     const uint32_t ob = la + kStuckDepth - ((code - D0) / T.NS + 1);
                     if (!(s_cap[ob >> 5] & (1u << (ob & 31u)))) continue;
-                    uint32_t v = code;
-                    for (uint32_t l = la; l < lbb; ++l) v = wave_step_slow(T, sc, edges, first, l, b.res, s_resume, v);
-                    b.ctab[c * D + code] = (uint16_t)v;
+                    b.ctab[c * D + code] = (uint16_t)wave_chain_slow(T, sc, edges, first, la, lbb, b.res, s_resume, code);
                 }
             }
             wave_sync_lds();
