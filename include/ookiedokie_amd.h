@@ -174,7 +174,13 @@ enum {
      * heads (identical bits; exists so the tests can run both). */
     OOKD_RX_FRONT_GRID = 1u << 6,
     /* Never pipeline a long capture in chunks (see pipeline_chunk_samples). */
-    OOKD_RX_NO_PIPELINE = 1u << 7
+    OOKD_RX_NO_PIPELINE = 1u << 7,
+    /* Front end, single-stage filters of up to 256 taps without decimation: by
+     * default the filter runs on the matrix cores (taps and samples split into
+     * fp16 pieces whose products are exact, fp32 accumulation, guard band +
+     * exact recompute as in the fused form: identical bits, floats within 1e-5).
+     * Set this for the packed-VALU loop instead (exists so the tests run both). */
+    OOKD_RX_FIR_VALU = 1u << 8
 };
 
 /* Contexts created with the same gate (and on the same device) queue their front-end kernels one

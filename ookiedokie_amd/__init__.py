@@ -43,6 +43,7 @@ RX_COUNT_QUIET = 16
 RX_SCAN_SIMS = 32
 RX_FRONT_GRID = 64
 RX_NO_PIPELINE = 128
+RX_FIR_VALU = 256
 DEFAULT_THRESHOLD = 0.1                 # ookiedokie_cfg.c:27
 DEFAULT_RATE = 3000000                  # ookiedokie_cfg.c:32
 DEFAULT_SAMPLES_PER_BUF = 8192          # ookiedokie_cfg.c:34
@@ -538,13 +539,14 @@ class Receiver:
                  message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
                  quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False,
                  front_grid: bool = False, pipeline: bool = True, pipeline_chunk_samples: int = 0,
-                 front_gate: Optional["FrontGate"] = None):
+                 front_gate: Optional["FrontGate"] = None, fir_valu: bool = False):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
                      | (RX_FSM_ROUNDS if fsm_rounds else 0) | (0 if quiet_skip else RX_NO_QUIET_SKIP)
                      | (RX_COUNT_QUIET if count_quiet else 0) | (RX_SCAN_SIMS if scan_sims else 0)
-                     | (RX_FRONT_GRID if front_grid else 0) | (0 if pipeline else RX_NO_PIPELINE))
+                     | (RX_FRONT_GRID if front_grid else 0) | (0 if pipeline else RX_NO_PIPELINE)
+                     | (RX_FIR_VALU if fir_valu else 0))
         cfg.threshold = threshold
         cfg.samples_per_buffer = samples_per_buffer
         cfg.max_samples = max_samples

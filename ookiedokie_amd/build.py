@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libookiedokie_amd.so")
 SOURCES = ["loaders.cpp", "rx.cpp", "synth.cpp", "stream_fir.cpp", "backend.cpp", "edges_fsm.hip", "fsm_scan.hip",
-           "formatter.cpp", "kernels.hip"]
+           "formatter.cpp", "kernels.hip", "fir_mfma.hip"]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,595 @@
+// fir_mfma.hip -- the 1-stage / decimation-1 front end on the matrix cores.
+//
+//   SC16Q11 unpack -> FIR -> |.|^2 >= P* -> packed bit words
+//   (reference: src/complexf.h:68-77, src/fir.c:302-334, src/ookiedokie.c:171-179)
+//
+// Why: the direct form of fir.c:313-318 is fp32 bound on this part -- 128 flop per
+// 4-byte sample with 32 taps (above the 19.7 flop/B ridge), 1020 with 255 taps -- and
+// the packed-VALU kernel (kernels.hip) tops out at half of the fp32 peak.  The matrix
+// cores run fp16 products with fp32 accumulation at 16 x the fp32 rate, and for THIS
+// filter the products can be made exact:
+//   * the samples are integers.  A nominal SC16Q11 sample (|x| <= 2048) is one fp16
+//     number exactly; any int16 splits exactly into x & ~31 (a multiple of 32, 11
+//     significant bits) + x & 31 -- two fp16 numbers;
+//   * a tap scaled by a power of two S splits into two fp16 pieces h1 + h2 that carry
+//     22 of its 24 significant bits -- 11 + 11 bits -- and usually all the filter needs:
+//     the host computes what is left over, exactly, and puts it into the error bound;
+//   * an 11-bit x 11-bit product is exact in fp32, so  y = c * sum (h1 + h2) * X  differs
+//     from the real sum only by the fp32 roundings of the accumulation -- like the
+//     reference's own sequential sum does (in another order).
+// The contract is the fused kernel's: the power is compared against a GUARD BAND
+// [p_lo, p_hi) around P* derived from a forward bound on |y_mfma - y_ref|, and a sample
+// that lands inside is recomputed in the reference's exact order (tap 0 first, separately
+// rounded multiply and add).  Bits are the reference's by construction; floats within
+// 1e-5 of the scale sum|h| max|x| (measured: a few 1e-7).
+//
+// The filter as a matrix product: a wave tile is 1024 outputs = 32 columns of 32
+// consecutive outputs.  With window sample j <-> input index t0 - Tp + j,
+//   y[32 n + i] = sum_kk A[i][kk] * win[32 n + kk],  A[i][kk] = h[i + Tp - kk]  (0 outside 0..T-1),
+// kk = 0 .. Tp + 31: a 32 x (Tp + 32) Toeplitz matrix of taps -- the SAME for every column
+// and every tile -- times a (Tp + 32) x 32 matrix whose column n is the window shifted by
+// 32 n.  v_mfma_f32_32x32x16_f16 takes 16 of the kk per instruction: KS = Tp / 16 + 2
+// K-steps, x 2 tap pieces x {re, im} (x 2 sample pieces for a tile that holds a sample
+// beyond +-2048).  The Toeplitz matrix holds T taps in Tp + 32 columns: 50 % of the
+// products are structural zeros with 32 taps, 11 % with 255 -- against a 16-fold rate.
+//   A fragments: constants, built by the host (mfma_prepare_taps), 4 VGPRs per K-step
+//                and piece, loaded once per workgroup and kept in registers over the
+//                workgroup's G consecutive tiles;
+//   B fragments: lane (n, half) reads the 8 consecutive window samples 32 n + 16 s +
+//                8 half of one plane (re or im) as fp16 from the wave's LDS window --
+//                one ds_read_b128; 8 pad halfs per 32 samples make the 16 lanes of a
+//                read group hit 16 different bank quads;
+//   C:           column on the lane, rows in the 16 registers: re and im of an output
+//                sit in the same lane and register, so power, threshold and guard band
+//                are per-lane VALU work, and a column's 32 bits are one lane pair's.
+// Everything around the product is the packed-VALU kernel's: raw non-temporal 16 B
+// loads, the quiet shortcut on the raw samples, sparse output with run stamps, tile
+// infos for the edge stage, no workgroup barrier (one wave = one workgroup).
+#include "kernels.hpp"
+
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace ookd {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// half index of window sample j inside a plane: 8 pad halfs per 32 samples
+__host__ __device__ constexpr uint32_t mslot(uint32_t j) { return j + 8u * (j >> 5); }
+
+template <int KS>
+struct MfmaGeom {
+    static constexpr uint32_t Tp = 16u * (KS - 2);              // tap history the window holds
+    static constexpr uint32_t W = kMfmaTile + Tp;               // window samples (a multiple of 32)
+    static constexpr uint32_t plane = mslot(W);                 // halfs per plane (a multiple of 8)
+    static constexpr uint32_t lds_bytes = plane * 2u * 2u;      // re + im
+    static constexpr uint32_t nvec = W / 4u;                    // 16 B raw vectors
+    static constexpr int rounds = (int)((nvec + 63u) / 64u);
+};
+
+typedef const __attribute__((address_space(1))) v4u *gptr128;
+__device__ __forceinline__ uint4 ld_nt4m(gptr128 p) {
+    const v4u v = __builtin_nontemporal_load(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// uniform base + 32-bit byte offset: lets the compiler use the SGPR-base addressing form instead of
+// keeping a 64-bit address per lane in registers (and hoisting a dozen of them out of the tile loop)
+typedef const __attribute__((address_space(1))) unsigned char *gbytes;
+typedef __attribute__((address_space(1))) unsigned char *gbytes_w;
+__device__ __forceinline__ uint4 ld_nt4_at(gbytes base, uint32_t byte_off) {
+    const v4u v = __builtin_nontemporal_load(reinterpret_cast<gptr128>(base + byte_off));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Keeps a uniform pointer in SGPRs and opaque: without it the compiler adds every lane's offset to it as a
+// 64-bit VGPR pair OUTSIDE the tile loop (a dozen pairs), runs out of registers and reloads them from scratch
+// in the loop head -- in front of the loads everything waits for.
+template <typename P>
+__device__ __forceinline__ P uniform_ptr(P ptr) {
+    uint64_t v = (uint64_t)ptr;
+    asm volatile("" : "+s"(v));
+    return (P)v;
+}
+
+__device__ __forceinline__ v2s as_v2sm(uint32_t w) { return __builtin_bit_cast(v2s, w); }
+
+typedef const __attribute__((address_space(1))) uint32_t *gptr32;
+typedef const __attribute__((address_space(1))) float *gptrf;
+
+// what the boundary handling needs, as scalars (a reference to the kernel's parameter block would put
+// the whole block on the stack)
+struct RawSrc {
+    gptr32 src;             // the capture
+    gptr32 halo;            // samples in front of it (newest last) or null
+    uint32_t halo_len;
+    uint64_t n_valid;       // samples present; beyond: zeros (bladeRF_file.c:113-117)
+};
+
+__device__ __forceinline__ uint32_t fetch_raw_m(const RawSrc &rs, int64_t n) {
+    if (n < 0) {
+        const int64_t h = (int64_t)rs.halo_len + n;
+        if (h < 0 || !rs.halo) return 0u;
+        return rs.halo[h];
+    }
+    if ((uint64_t)n >= rs.n_valid) return 0u;
+    return rs.src[n];
+}
+
+// Reference-order recomputation of output `n` (= input index: one stage, decimation 1)
+// from the capture itself: fir.c:313-318, separately rounded multiply and add.
+__device__ __forceinline__ float2 mfma_exact_output(const RawSrc &rs, gptrf taps, uint32_t T, int64_t n) {
+    const float s = 1.0f / 2048.0f;
+    float re = 0.0f, im = 0.0f;
+    for (uint32_t k = 0; k < T; ++k) {
+        const uint32_t w = fetch_raw_m(rs, n - (int64_t)k);
+        const float xr = (float)(int16_t)(w & 0xffffu) * s;
+        const float xi = (float)(int16_t)(w >> 16) * s;
+        const float t = taps[k];
+        const float pr = t * xr;
+        const float pi = t * xi;
+        re = re + pr;
+        im = im + pi;
+    }
+    return make_float2(re, im);
+}
+
+// four raw samples (I | Q << 16 each), masked, -> four fp16 I and four fp16 Q (exact: see top)
+__device__ __forceinline__ void cvt4(uint4 q, uint32_t mask, h4 &re, h4 &im) {
+    const uint32_t w0 = q.x & mask, w1 = q.y & mask, w2 = q.z & mask, w3 = q.w & mask;
+    re = (h4){(_Float16)(short)(w0 & 0xffffu), (_Float16)(short)(w1 & 0xffffu), (_Float16)(short)(w2 & 0xffffu),
+              (_Float16)(short)(w3 & 0xffffu)};
+    im = (h4){(_Float16)(short)(w0 >> 16), (_Float16)(short)(w1 >> 16), (_Float16)(short)(w2 >> 16),
+              (_Float16)(short)(w3 >> 16)};
+}
+
+// Workgroup = kMfmaWaves wavefronts that share ONE copy of the A-fragment image in LDS (8 KB with 32
+// taps, 36 KB with 255) and otherwise work alone: each wave pulls tiles of the workgroup's chunk
+// (FrontParams::mfma_g consecutive tiles) from a ticket in LDS, so a wave that drew loud tiles does not hold
+// the others up, and a quiet chunk costs nothing but its loads.  The image is fetched by the first wave
+// that meets a loud tile (another wave doing the same at the same time stores the same bytes); `a_ready`
+// is set behind that wave's own stores -- the LDS executes a wave's accesses in order.  No workgroup
+// barrier after the one that publishes the zeroed ticket.
+// Registers: 32 accumulators + A / B fragments streaming through + the raw window while it is waited for
+// (dead before the product starts: a tile with samples beyond +-2048 fetches it again for its second pass).
+constexpr int kMfmaWaves = 4;
+constexpr uint32_t kMfmaCtlBytes = 16;
+
+template <int KS>
+__host__ __device__ constexpr uint32_t mfma_lds_bytes() {
+    return (uint32_t)KS * 2u * 1024u + kMfmaCtlBytes + (uint32_t)kMfmaWaves * MfmaGeom<KS>::lds_bytes;
+}
+
+template <int KS, bool PRE>
+__global__ __launch_bounds__(64 * kMfmaWaves) __attribute__((amdgpu_waves_per_eu(PRE ? 4 : 5)))
+void fir1_mfma_kernel(const FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using Gm = MfmaGeom<KS>;
+    constexpr uint32_t Tp = Gm::Tp;
+    constexpr uint32_t kImgBytes = (uint32_t)KS * 2u * 1024u;
+    uint32_t tid = threadIdx.x & 63u;       // (re-derived every tile: see the loop head)
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t n = tid & 31u, hh = tid >> 5;
+    const uint32_t cap = blockIdx.y;
+    RawSrc rs;
+    rs.src = (gptr32)(reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride);
+    rs.halo = (gptr32)reinterpret_cast<const uint32_t *>(p.halo);
+    rs.halo_len = p.halo_len;
+    rs.n_valid = p.n_valid;
+    const gptr32 src = rs.src;
+    typedef __attribute__((address_space(1))) uint64_t *gptr64;
+    typedef __attribute__((address_space(1))) uint32_t *gptr32w;
+    const gptr64 words = (gptr64)(p.bits + (uint64_t)cap * p.words_per_cap);
+    const gptr32w tile_info = (gptr32w)(p.tile_info + (uint64_t)cap * p.tiles_per_cap);
+    const h8 *a_img = reinterpret_cast<const h8 *>(smem_raw);
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(smem_raw + kImgBytes);      // [0] next tile of the chunk, [1] image ready
+    unsigned char *win = smem_raw + kImgBytes + kMfmaCtlBytes + wave * Gm::lds_bytes;
+    _Float16 *pl_re = reinterpret_cast<_Float16 *>(win);
+    _Float16 *pl_im = pl_re + Gm::plane;
+    const bool aligned16 = (((uintptr_t)src & 15u) == 0);
+    typedef float v2fm __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) v2fm *gptrf2;
+    const gptrf2 fout = p.fir_out ? (gptrf2)(reinterpret_cast<v2fm *>(p.fir_out) + (uint64_t)cap * p.n_out) : (gptrf2)nullptr;
+
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = 0;
+    }
+    __syncthreads();
+
+    // ticket k of workgroup b is tile k * gridDim + b: the workgroups that are resident together (consecutive b,
+    // at about the same k) read one dense, moving window of the capture, like a hardware-dispatched grid of
+    // one-tile workgroups does.
+    // Software pipeline: the raw window of the NEXT tile is requested as soon as this tile's has arrived,
+    // before any of this tile's work -- a wave always has a window in flight.  (Anything that puts a second
+    // dependent memory round trip in front of those loads -- a register spilled to scratch and reloaded in
+    // the loop head, a ticket in global memory -- costs a whole loaded-memory latency per tile: measured
+    // 4.3 us per tile and wave instead of 1.7.)
+    auto take_ticket = [&](uint64_t &tile) -> bool {
+        uint32_t tk = 0;
+        if (tid == 0) tk = __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        tile = (uint64_t)tk * gridDim.x + blockIdx.x + p.tile_base;
+        return tk < p.mfma_g && tile < p.tile_end;
+    };
+    auto is_interior = [&](uint64_t tile) -> bool {
+        const uint64_t t0 = tile * kMfmaTile;
+        return aligned16 && t0 >= Tp && t0 + kMfmaTile <= p.n_valid;
+    };
+    // vector v <-> input samples t0 - Tp + 4v .. + 3
+    auto issue_loads = [&](uint64_t tile, uint4 (&q)[Gm::rounds]) {
+        const gbytes src4 = uniform_ptr((gbytes)(src + (tile * kMfmaTile - Tp)));
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            // (a partial last round: the lanes past the window read its last vector again -- same cache line,
+            //  harmless to the min / max below, never stored; a branch here would need its own address)
+            q[i] = ld_nt4_at(src4, 16u * ((64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? v : Gm::nvec - 1u));
+        }
+    };
+    // first / last tiles of a capture, halo of a shard, unaligned pointers: sample by sample, staged raw
+    // through the (free) LDS window so that the code stays a compact loop
+    auto boundary_loads = [&](uint64_t tile, uint4 (&q)[Gm::rounds]) {
+        const uint64_t t0 = tile * kMfmaTile;
+        uint4 *stage = reinterpret_cast<uint4 *>(win);
+#pragma unroll 1
+        for (uint32_t v = tid; v < Gm::nvec; v += 64u) {
+            const int64_t s0 = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
+            uint4 w;
+            w.x = fetch_raw_m(rs, s0);
+            w.y = fetch_raw_m(rs, s0 + 1);
+            w.z = fetch_raw_m(rs, s0 + 2);
+            w.w = fetch_raw_m(rs, s0 + 3);
+            stage[v] = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            q[i] = (64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? stage[v] : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // raw window -> fp16 planes in LDS (masked: a wide tile's upper / lower bits), then the K-steps
+    auto product = [&](const uint4 (&q)[Gm::rounds], uint32_t mask, f16x &are, f16x &aim) {
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) {
+            const uint32_t v = tid + 64u * i;
+            if (64u * (i + 1) <= Gm::nvec || v < Gm::nvec) {
+                h4 r4, i4;
+                cvt4(q[i], mask, r4, i4);
+                *reinterpret_cast<h4 *>(pl_re + mslot(4u * v)) = r4;
+                *reinterpret_cast<h4 *>(pl_im + mslot(4u * v)) = i4;
+            }
+        }
+        // the window is private to this wavefront and the LDS executes one wave's accesses in
+        // order: no workgroup barrier, only keep the compiler from moving reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const _Float16 *bre = pl_re + 40u * n + 8u * hh;
+        const _Float16 *bim = pl_im + 40u * n + 8u * hh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const h8 xr = *reinterpret_cast<const h8 *>(bre + 16 * s + 8 * (s >> 1));
+            const h8 xi = *reinterpret_cast<const h8 *>(bim + 16 * s + 8 * (s >> 1));
+            const h8 a0 = a_img[(s * 2 + 0) * 64 + tid];
+            const h8 a1 = a_img[(s * 2 + 1) * 64 + tid];
+            are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xr, are, 0, 0, 0);
+            aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xi, aim, 0, 0, 0);
+            are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xr, are, 0, 0, 0);
+            aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xi, aim, 0, 0, 0);
+        }
+        // the next pass / tile rewrites the window: the reads above are done (the LDS is in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    uint64_t tile = 0;
+    if (!take_ticket(tile)) return;
+    uint4 q[Gm::rounds];
+    if (is_interior(tile)) issue_loads(tile, q);
+    else boundary_loads(tile, q);
+    for (;;) {
+        // Everything per lane below is a function of the lane id; left alone the compiler computes a dozen
+        // offsets and addresses from it ONCE, keeps them alive across the whole loop and, out of registers,
+        // reloads them from scratch right in front of the loads.  Opaque lane id => recomputed per tile
+        // (a handful of VALU instructions), one live register.
+        asm volatile("" : "+v"(tid));
+        n = tid & 31u;
+        hh = tid >> 5;
+        const uint64_t t0 = tile * kMfmaTile;
+        // ---- quiet test (exact: kernels.hip) and range of the window ------------------------------
+        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) {
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2sm(q[i].x), as_v2sm(q[i].y)));
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2sm(q[i].z), as_v2sm(q[i].w)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2sm(q[i].x), as_v2sm(q[i].y)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2sm(q[i].z), as_v2sm(q[i].w)));
+        }
+        const int L = p.quiet_lsb;
+        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+        const bool quiet = (!fout && __ballot(loud) == 0) || (p.mfma_debug & 1u);
+        const bool wide = __ballot(mx.x > 2047 || mx.y > 2047 || mn.x < -2048 || mn.y < -2048) != 0;
+
+        // ---- the next tile's window: in flight during everything below -----------------------------
+        uint64_t tile_n = 0;
+        const bool more = take_ticket(tile_n);
+        const bool pre = PRE && more && is_interior(tile_n);
+        uint4 qn[Gm::rounds];
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) qn[i] = make_uint4(0, 0, 0, 0);
+        if (pre) issue_loads(tile_n, qn);
+
+        if (quiet) {
+            if (!p.sparse) {
+                if (tid < kMfmaTile / 64) *reinterpret_cast<gptr64>(uniform_ptr((gbytes_w)(words + (t0 >> 6))) + 8u * tid) = 0;
+                if (tid == 0) *uniform_ptr(tile_info + tile) = 0;
+            }
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + ((blockIdx.x * kMfmaWaves + wave) % kQuietCounters), 1u);
+        } else {
+            if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+                // the A-fragment image -> LDS (see above: idempotent, flag behind this wave's own stores)
+                // (four fragments per turn in flight; not unrolled further: every unrolled load would keep a
+                //  hoisted 64-bit address pair alive across the whole tile loop)
+                v4u *dst = reinterpret_cast<v4u *>(smem_raw) + tid;
+                gbytes img = uniform_ptr((gbytes)p.mfma_a);
+#pragma unroll 1
+                for (int i = 0; i < 2 * KS; i += 4) {
+                    img = uniform_ptr(img);
+                    const gptr128 s4 = reinterpret_cast<gptr128>(img + 16u * tid);
+                    const v4u f0 = s4[0], f1 = s4[64], f2 = s4[128], f3 = s4[192];
+                    dst[0] = f0;
+                    dst[64] = f1;
+                    dst[128] = f2;
+                    dst[192] = f3;
+                    dst += 256;
+                    img += 4096;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            f16x are, aim;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                are[r] = 0.0f;
+                aim[r] = 0.0f;
+            }
+            if (!wide) {
+                product(q, 0xffffffffu, are, aim);
+            } else {
+                // a sample beyond +-2048 somewhere in the window: upper bits, then the low five bits
+                product(q, 0xffe0ffe0u, are, aim);
+                product(q, 0x001f001fu, are, aim);
+            }
+
+        // ---- power, threshold, guard band: register r of lane (n, hh) is output 32 n + row(r) ------
+        const float c = p.mfma_c;
+        const float plo = wide ? p.p_lo_w : p.p_lo_n;
+        const float phi = wide ? p.p_hi_w : p.p_hi_n;
+        const uint32_t ocol = 32u * n + 4u * hh;
+        uint32_t m16 = 0, u16 = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float yr = are[r] * c, yi = aim[r] * c;
+            are[r] = yr;
+            aim[r] = yi;
+            const float rr = yr * yr, ii = yi * yi;
+            const float pw = rr + ii;
+            const bool hi = pw >= phi;
+            m16 |= (hi ? 1u : 0u) << r;
+            u16 |= ((!hi && pw >= plo) ? 1u : 0u) << r;
+        }
+        if (__ballot(u16 != 0) != 0) {
+            uint32_t todo = u16, redo = 0;
+            while (todo) {
+                const uint32_t r = (uint32_t)__ffs((int)todo) - 1u;
+                todo &= todo - 1u;
+                const uint64_t o = t0 + ocol + (r & 3u) + 8u * (r >> 2);
+                if (o >= p.n_out) continue;
+                const float2 y = mfma_exact_output(rs, (gptrf)p.taps, p.stage[0].ntaps, (int64_t)o);
+                const float rr = y.x * y.x, ii = y.y * y.y;
+                const float pe = rr + ii;
+                m16 = (m16 & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
+                redo++;
+            }
+            if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
+        }
+        if (fout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t o = t0 + ocol + (r & 3) + 8 * (r >> 2);
+                if (o < p.n_out) fout[o] = (v2fm){are[r], aim[r]};
+            }
+        }
+
+        // ---- 32 bits per column: rows (r & 3) + 8 (r >> 2) + 4 hh ---------------------------------
+        uint32_t m32 = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
+        m32 <<= 4u * hh;
+        uint32_t w32 = m32 | (uint32_t)__shfl_xor((int)m32, 32);
+        {
+            // outputs past the end of the (padded) capture do not exist
+            const uint64_t c0 = t0 + 32u * n;
+            if (c0 + 32u > p.n_out) {
+                const uint32_t keep = c0 >= p.n_out ? 0u : (uint32_t)(p.n_out - c0);
+                w32 &= (1u << keep) - 1u;       // keep < 32 here
+            }
+        }
+        // level changes inside the tile (the tile's first bit against the tile before NOT included)
+        {
+            const uint32_t prev_top = (uint32_t)__shfl_up((int)(w32 >> 31), 1);
+            uint32_t ch = w32 ^ (w32 << 1);
+            if (n != 0) ch ^= prev_top & 1u;
+            else ch &= ~1u;
+            uint32_t cnt = hh == 0 ? (uint32_t)__popc(ch) : 0u;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w32 & 1u));
+            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(w32 >> 31), 31);
+            if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+        }
+        const uint32_t up = (uint32_t)__shfl_xor((int)w32, 1);
+        if (hh == 0 && (n & 1u) == 0) {
+            const gbytes_w wb = uniform_ptr((gbytes_w)(words + (t0 >> 6)));
+            *reinterpret_cast<gptr64>(wb + 4u * n) = (uint64_t)w32 | ((uint64_t)up << 32);
+        }
+        }   // loud tile
+
+        if (!more) break;
+        if (!pre) {
+            if (is_interior(tile_n)) issue_loads(tile_n, qn);
+            else boundary_loads(tile_n, qn);
+        }
+#pragma unroll
+        for (int i = 0; i < Gm::rounds; ++i) q[i] = qn[i];
+        tile = tile_n;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+static uint16_t half_bits(_Float16 h) {
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+
+static int mfma_ksteps_for(uint32_t ntaps) {
+    // compiled window lengths: Tp = 32, 64, 128, 256 (history of Tp >= T - 1 samples)
+    if (ntaps == 0) return 0;
+    if (ntaps <= 32) return 4;
+    if (ntaps <= 64) return 6;
+    if (ntaps <= 128) return 10;
+    if (ntaps <= 256) return 18;
+    return 0;
+}
+
+bool mfma_prepare_taps(const float *taps, uint32_t ntaps, MfmaTaps &out) {
+    out = MfmaTaps();
+    const int KS = mfma_ksteps_for(ntaps);
+    if (KS == 0) return false;
+    double hmax = 0.0, sum_abs = 0.0;
+    for (uint32_t k = 0; k < ntaps; ++k) {
+        if (!std::isfinite(taps[k])) return false;
+        hmax = std::max(hmax, std::fabs((double)taps[k]));
+        sum_abs += std::fabs((double)taps[k]);
+    }
+    if (!(hmax > 0.0)) return false;
+    int e = 0;
+    (void)std::frexp(hmax, &e);                 // hmax = m * 2^e, m in [0.5, 1)
+    const int sh = 15 - e;                      // hmax * 2^sh in [2^14, 2^15)
+    // c = 2^-11 / S must be a normal float, and so must S itself
+    if (sh > 100 || sh < -100) return false;
+    const double S = std::ldexp(1.0, sh);
+    const double kMinNormal = std::ldexp(1.0, -14);
+    std::vector<_Float16> p1(ntaps), p2(ntaps);
+    double delta = 0.0, sum_hat = 0.0;
+    for (uint32_t k = 0; k < ntaps; ++k) {
+        const double hs = (double)taps[k] * S;          // exact: a power of two
+        _Float16 a = (_Float16)hs;
+        if (std::fabs((double)a) < kMinNormal) a = (_Float16)0.0;       // no fp16 subnormals on the matrix cores
+        const double r1 = hs - (double)a;
+        _Float16 b = (_Float16)r1;
+        if (std::fabs((double)b) < kMinNormal) b = (_Float16)0.0;
+        const double r2 = r1 - (double)b;
+        if (!std::isfinite((double)a) || !std::isfinite((double)b)) return false;
+        p1[k] = a;
+        p2[k] = b;
+        delta += std::fabs(r2) / S;
+        sum_hat += std::fabs((double)a + (double)b) / S;
+    }
+    const uint32_t Tp = 16u * (uint32_t)(KS - 2);
+    out.ksteps = (uint32_t)KS;
+    out.image.assign((size_t)KS * 2 * 64 * 8, 0);
+    for (int s = 0; s < KS; ++s) {
+        for (int pc = 0; pc < 2; ++pc) {
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t r = l & 31u, hh = l >> 5;
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const int64_t kk = 16 * s + 8 * (int64_t)hh + j;
+                    const int64_t t = (int64_t)r + Tp - kk;
+                    _Float16 v = (_Float16)0.0;
+                    if (t >= 0 && t < (int64_t)ntaps) v = pc == 0 ? p1[t] : p2[t];
+                    out.image[(((size_t)s * 2 + pc) * 64 + l) * 8 + j] = half_bits(v);
+                }
+            }
+        }
+    }
+    out.c = (float)std::ldexp(1.0, -11 - sh);
+    out.delta = delta;
+    out.sum_abs = sum_abs;
+    out.sum_hat = sum_hat;
+    return true;
+}
+
+double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide) {
+    // |y_mfma - y_ref| per component, x in units of 1 (= 2048 LSB):
+    //   reference chain against the real sum: (T + 1) u sum|h| xmax   (T products, T sums)
+    //   matrix-core accumulation against the real sum of the split taps: every product enters
+    //   through one addition; allow each of them a full truncation (2 u) of a partial sum that is
+    //   bounded by sum|h^| xmax:  chain length = K-steps x 16 x pieces (x 2 sample pieces)
+    //   taps not captured by the two pieces: delta xmax
+    const double u = std::ldexp(1.0, -24);
+    const double xmax = wide ? 16.0 : 1.0;
+    const double chain = (double)t.ksteps * 16.0 * 2.0 * (wide ? 2.0 : 1.0);
+    const double e_ref = ((double)ntaps + 1.0) * u * t.sum_abs;
+    const double e_acc = chain * 2.0 * u * t.sum_hat;
+    return 1.1 * (e_ref + e_acc + t.delta) * xmax + (double)ntaps * std::ldexp(1.0, -140);
+}
+
+bool front_uses_mfma(const FrontParams &p) {
+    return p.mfma_a != nullptr && p.num_stages == 1 && p.stage[0].decim == 1 && p.origin == 0 && !p.iq_f32 &&
+           mfma_ksteps_for(p.stage[0].ntaps) != 0;
+}
+
+template <int KS>
+static hipError_t launch_mfma_ks(FrontParams &pp, uint32_t num_captures, uint64_t grid, hipStream_t stream,
+                                 hipEvent_t t0, hipEvent_t t1) {
+    const void *fn = (pp.mfma_debug & 2u) ? reinterpret_cast<const void *>(&fir1_mfma_kernel<KS, false>)
+                                          : reinterpret_cast<const void *>(&fir1_mfma_kernel<KS, true>);
+    const size_t lds = mfma_lds_bytes<KS>();
+    hipError_t e = ensure_dynamic_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    void *args[] = {&pp};
+    e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kMfmaWaves), args, lds, stream, t0, t1, 0);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
+                             hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count) {
+    // whole 4096-output blocks, so every bit word of the capture is written (dense output)
+    const uint64_t all = (p.n_out + kFirTile - 1) / kFirTile * (kFirTile / kMfmaTile);
+    const uint64_t b = tile_begin < all ? tile_begin : all;
+    const uint64_t cnt = tile_count < all - b ? tile_count : all - b;
+    if (cnt == 0) return hipSuccess;
+    FrontParams pp = p;
+    pp.tile_base = (uint32_t)b;
+    pp.tile_end = b + cnt;
+    if (pp.mfma_g == 0) pp.mfma_g = 1;
+    const uint64_t grid = (cnt + pp.mfma_g - 1) / pp.mfma_g;
+    switch (mfma_ksteps_for(p.stage[0].ntaps)) {
+    case 4: return launch_mfma_ks<4>(pp, num_captures, grid, stream, t0, t1);
+    case 6: return launch_mfma_ks<6>(pp, num_captures, grid, stream, t0, t1);
+    case 10: return launch_mfma_ks<10>(pp, num_captures, grid, stream, t0, t1);
+    case 18: return launch_mfma_ks<18>(pp, num_captures, grid, stream, t0, t1);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ookd

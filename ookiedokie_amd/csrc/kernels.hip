@@ -1134,6 +1134,7 @@ __global__ __launch_bounds__(256) void synth_kernel(const SynthRun *runs, uint64
 
 // small tiles only pay through the quiet shortcut: none without it (quiet_lsb 0)
 static int fir1_R(const FrontParams &p) {
+    if (front_uses_mfma(p)) return (int)kMfmaTile / 64;
     return (p.stage[0].ntaps_pad <= kFir1ShortTaps && p.quiet_lsb > 0) ? kFir1RShort : kFir1RLong;
 }
 
@@ -1265,6 +1266,9 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
                                                 dim3((uint32_t)grid, num_captures), dim3(64), args, 0, stream, t0, t1, 0);
         return e != hipSuccess ? e : hipGetLastError();
     }
+    if (use_fir1(p) && front_uses_mfma(p) && !exact) {
+        return launch_front_mfma(p, num_captures, stream, t0, t1, tile_begin, tile_count);
+    }
     if (use_fir1(p)) {
         const size_t lds = fir1_lds_bytes(p);
         // whole 4096-output blocks, so every bit word of the capture is written
@@ -1279,9 +1283,11 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
             fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RLong>)
                        : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RLong>);
         }
-        hipError_t e = ensure_dynamic_lds(fn, lds);
+        static const size_t lds_pad = getenv("OOKD_FIR1_LDS_PAD") ? (size_t)atoi(getenv("OOKD_FIR1_LDS_PAD")) : 0;   // experiment: caps the waves per CU
+        const size_t lds_req = lds + lds_pad;
+        hipError_t e = ensure_dynamic_lds(fn, lds_req);
         if (e != hipSuccess) return e;
-        e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kFirWgWaves), args, lds, stream, t0, t1, 0);
+        e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kFirWgWaves), args, lds_req, stream, t0, t1, 0);
         return e != hipSuccess ? e : hipGetLastError();
     }
     if (use_fir2(p)) {
@@ -1308,7 +1314,7 @@ bool front_sparse_capable(const FrontParams &p) {
 }
 
 bool front_streams(const FrontParams &p) {
-    return use_fir1(p) && fir1_R(p) == kFir1RShort && p.stage[0].ntaps_pad <= 256u;
+    return !front_uses_mfma(p) && use_fir1(p) && fir1_R(p) == kFir1RShort && p.stage[0].ntaps_pad <= 256u;
 }
 
 static int device_cu_count() {

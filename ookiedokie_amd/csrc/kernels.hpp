@@ -67,6 +67,14 @@ struct FrontParams {
     uint32_t sparse;            // tuned 1-stage kernels: quiet tiles store nothing -- what an earlier run left in
                                 // their words / infos carries that run's stamp and reads as quiet (tile_live)
     uint32_t stamp_bits;        // this run's stamp << kTileStampShift, OR-ed into every tile info written
+    // matrix-core form of the 1-stage kernel (fir_mfma.hip); mfma_a == null: packed-VALU form
+    const void *mfma_a;         // A-fragment image of the split taps (mfma_prepare_taps)
+    float mfma_c;               // accumulator * mfma_c = filter output
+    float p_lo_n, p_hi_n;       // guard band of a tile whose samples all lie within +-2048 (one sample piece)
+    float p_lo_w, p_hi_w;       // ... of a tile with samples beyond (two sample pieces)
+    uint32_t mfma_g;            // consecutive wave tiles per workgroup (the A fragments are loaded once for them)
+    uint64_t tile_end;          // first wave tile past this launch (set by launch_front_mfma)
+    uint32_t mfma_debug;        // experiments (OOKD_MFMA_DEBUG): bit 0 = every tile takes the quiet exit (timing only)
 };
 
 // A tile info word:  level changes inside the tile (10 bits: tiles hold at most 1024 outputs)
@@ -106,6 +114,25 @@ struct StreamCtl {
     uint32_t num_heads;         // filled in by the launcher
     uint32_t static_stride;     // experiment: groups dealt statically (workgroup + k * grid) instead of by ticket
 };
+
+// ---- matrix-core form of the tuned 1-stage front end (fir_mfma.hip) ---------------------
+constexpr uint32_t kMfmaTile = 1024;    // outputs per wave tile: 32 columns x 32 rows of v_mfma_f32_32x32x16_f16
+
+struct MfmaTaps {
+    std::vector<uint16_t> image;    // [K-steps][2 pieces][64 lanes][8] fp16 bit patterns
+    uint32_t ksteps = 0;
+    float c = 0.0f;                 // accumulator -> filter output
+    double delta = 0.0;             // sum |h - (h1 + h2) / S|: what the two pieces do not carry
+    double sum_abs = 0.0;           // sum |h|
+    double sum_hat = 0.0;           // sum |h1 + h2| / S
+};
+// false: this filter does not go through the matrix cores (more than 256 taps, non-finite taps, ...)
+bool mfma_prepare_taps(const float *taps, uint32_t ntaps, MfmaTaps &out);
+// forward bound on |y_mfma - y_ref| per component (filter output units)
+double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide);
+bool front_uses_mfma(const FrontParams &p);
+hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
+                             hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a kernel needs
 // more than it was last granted (the call costs microseconds per launch).

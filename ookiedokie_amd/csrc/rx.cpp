@@ -117,6 +117,7 @@ float power_threshold(float thr) {
 // inputs that already differ by e_s, which the stage amplifies by at most
 // sum|h_{s+1}|, and add their own rounding difference on values bounded by
 // 16 * prod sum|h|:  e = 2.2 u * 16 * prod_s S_s * sum_s (T_s + 1).
+void band_from_error(double e, float p_star, float &p_lo, float &p_hi);
 void guard_band(const std::vector<std::vector<float>> &stages, float p_star, float &p_lo, float &p_hi) {
     if (std::isnan(p_star) || std::isinf(p_star) || p_star <= 0.0f) {
         p_lo = p_hi = p_star;
@@ -132,6 +133,16 @@ void guard_band(const std::vector<std::vector<float>> &stages, float p_star, flo
         Tsum += (double)taps.size();
     }
     const double e = 2.2 * T * u * S * 16.0 * (stages.size() > 1 ? 1.01 : 1.0) + Tsum * std::ldexp(1.0, -140);
+    band_from_error(e, p_star, p_lo, p_hi);
+}
+
+// [p_lo, p_hi) around p_star for a filter output known to within e per component
+void band_from_error(double e, float p_star, float &p_lo, float &p_hi) {
+    if (std::isnan(p_star) || std::isinf(p_star) || p_star <= 0.0f) {
+        p_lo = p_hi = p_star;
+        return;
+    }
+    const double u = std::ldexp(1.0, -24);
     const double P = (double)p_star;
     // |p_ref - p_fma| <= m(p) = 3.003*e*sqrt(p) + 3e^2 + 6u*p
     // upper edge: smallest s = sqrt(p) with (1-6u)s^2 - 3.003e s - (3e^2 + P) >= 0
@@ -267,6 +278,10 @@ struct ookd_rx {
     std::vector<float> taps0;       // stage-0 true taps (guard band)
     DevBuf<float> d_taps;
     float p_star = 0, p_lo = 0, p_hi = 0;
+    // matrix-core form of the 1-stage front end (fir_mfma.hip): A-fragment image, scale, bands; empty = packed-VALU form
+    DevBuf<uint16_t> d_mfma_a;
+    float mfma_c = 0, p_lo_n = 0, p_hi_n = 0, p_lo_w = 0, p_hi_w = 0;
+    uint32_t mfma_g = 0;
     int quiet_lsb = 0;              // 0 = the quiet shortcut never applies
     bool exact = false;
     bool count_quiet = false;
@@ -388,6 +403,7 @@ struct ookd_rx {
         }
         (void)hipSetDevice(dev);
         d_taps.release();
+        d_mfma_a.release();
         d_tables.release();
         d_bits.release();
         d_fir.release();
@@ -478,6 +494,17 @@ struct ookd_rx {
         p.p_star = p_star;
         p.p_lo = p_lo;
         p.p_hi = p_hi;
+        p.mfma_a = d_mfma_a.p;
+        p.mfma_c = mfma_c;
+        p.p_lo_n = p_lo_n;
+        p.p_hi_n = p_hi_n;
+        p.p_lo_w = p_lo_w;
+        p.p_hi_w = p_hi_w;
+        p.mfma_g = mfma_g;
+        {
+            static const uint32_t dbg = getenv("OOKD_MFMA_DEBUG") ? (uint32_t)atoi(getenv("OOKD_MFMA_DEBUG")) : 0u;
+            p.mfma_debug = dbg;
+        }
         p.recompute_count = &d_hdr.p->recompute;
         p.quiet_lsb = quiet_lsb;
         p.quiet_count = count_quiet ? d_quiet.p : nullptr;
@@ -1393,6 +1420,24 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         std::vector<std::vector<float>> st;
         for (const auto &f : filter->stages) st.push_back(f.taps);
         guard_band(st, rx->p_star, rx->p_lo, rx->p_hi);
+        // 1 stage, decimation 1, <= 256 taps: the product runs on the matrix cores (fir_mfma.hip) unless the
+        // caller asks for the packed-VALU loop (or for the experimental streaming form, which only exists for it)
+        MfmaTaps mt;
+        if (rx->num_stages == 1 && rx->stage[0].decim == 1 && !(cfg->flags & OOKD_RX_FIR_VALU) &&
+            !getenv("OOKD_FRONT_STREAM") && !getenv("OOKD_FIR_VALU") &&
+            mfma_prepare_taps(filter->stages[0].taps.data(), rx->stage[0].ntaps, mt)) {
+            if (rx->d_mfma_a.alloc(mt.image.size()) != OOKD_OK) return nullptr;
+            if (hipMemcpy(rx->d_mfma_a.p, mt.image.data(), mt.image.size() * sizeof(uint16_t),
+                          hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("tap image upload failed");
+                return nullptr;
+            }
+            rx->mfma_c = mt.c;
+            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, false), rx->p_star, rx->p_lo_n, rx->p_hi_n);
+            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, true), rx->p_star, rx->p_lo_w, rx->p_hi_w);
+            rx->mfma_g = 16;        // wave tiles per (4-wave) workgroup
+            if (const char *g = getenv("OOKD_MFMA_G")) rx->mfma_g = (uint32_t)std::min(4096, std::max(1, atoi(g)));
+        }
     }
     if (filter && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) && !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
         // |y_re|, |y_im| <= S * m with S = prod over stages of sum|h|, m = max |component| in
