@@ -52,6 +52,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -60,6 +61,7 @@ namespace ookd {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16x __attribute__((ext_vector_type(16)));
+typedef float v2fm __attribute__((ext_vector_type(2)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
@@ -153,14 +155,25 @@ __device__ __forceinline__ void cvt4(uint4 q, uint32_t mask, h4 &re, h4 &im) {
 }
 
 // Workgroup = kMfmaWaves wavefronts that share ONE copy of the A-fragment image in LDS (8 KB with 32
-// taps, 36 KB with 255) and otherwise work alone: each wave pulls tiles of the workgroup's chunk
-// (FrontParams::mfma_g consecutive tiles) from a ticket in LDS, so a wave that drew loud tiles does not hold
-// the others up, and a quiet chunk costs nothing but its loads.  The image is fetched by the first wave
-// that meets a loud tile (another wave doing the same at the same time stores the same bytes); `a_ready`
-// is set behind that wave's own stores -- the LDS executes a wave's accesses in order.  No workgroup
-// barrier after the one that publishes the zeroed ticket.
-// Registers: 32 accumulators + A / B fragments streaming through + the raw window while it is waited for
-// (dead before the product starts: a tile with samples beyond +-2048 fetches it again for its second pass).
+// taps, 36 KB with 255) and otherwise work alone: each wave pulls tiles (FrontParams::mfma_g per workgroup)
+// from a ticket in LDS, so a wave that drew loud tiles does not hold the others up, and a quiet tile costs
+// nothing but its loads.  The image is fetched by the first wave that meets a loud tile (another wave
+// doing the same at the same time stores the same bytes); the ready flag is set behind that wave's own
+// stores -- the LDS executes a wave's accesses in order.  No workgroup barrier after the one that
+// publishes the zeroed ticket.
+//
+// Ticket k of workgroup b is tile k * gridDim + b: the workgroups that are resident together (consecutive
+// b, at about the same k) read one dense, moving window of the capture, like a hardware-dispatched grid
+// of one-tile workgroups does.
+//
+// Software pipeline: the next tile's raw window is requested as soon as this tile's raw samples are dead
+// -- at once for a quiet tile, behind the (last) conversion for a loud one -- into the same registers; it
+// is in flight during the product and everything behind it.  (Anything that puts a second dependent
+// memory round trip in front of those loads -- a register spilled to scratch and reloaded in the loop
+// head, a ticket in global memory -- costs a whole loaded-memory latency per tile: measured 4.3 us per
+// tile and wave instead of 1.7.)
+//
+// Registers (96: five waves per SIMD): 32 accumulators + two A / B fragment sets + the raw window.
 constexpr int kMfmaWaves = 4;
 constexpr uint32_t kMfmaCtlBytes = 16;
 
@@ -169,147 +182,197 @@ __host__ __device__ constexpr uint32_t mfma_lds_bytes() {
     return (uint32_t)KS * 2u * 1024u + kMfmaCtlBytes + (uint32_t)kMfmaWaves * MfmaGeom<KS>::lds_bytes;
 }
 
-template <int KS, bool PRE>
-__global__ __launch_bounds__(64 * kMfmaWaves) __attribute__((amdgpu_waves_per_eu(PRE ? 4 : 5)))
+struct MfmaTileCtx {            // uniform per workgroup
+    RawSrc rs;
+    uint32_t *ctl;              // LDS: [0] next ticket, [1] image ready
+    uint32_t tickets;           // per workgroup
+    uint64_t tile_base, tile_end;
+    bool aligned16;
+};
+
+__device__ __forceinline__ bool mfma_take_ticket(const MfmaTileCtx &c, uint32_t tid, uint64_t &tile) {
+    uint32_t tk = 0;
+    if (tid == 0) tk = __hip_atomic_fetch_add(&c.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    tile = (uint64_t)tk * gridDim.x + blockIdx.x + c.tile_base;
+    return tk < c.tickets && tile < c.tile_end;
+}
+
+template <int KS>
+__device__ __forceinline__ bool mfma_interior(const MfmaTileCtx &c, uint64_t tile) {
+    const uint64_t t0 = tile * kMfmaTile;
+    return c.aligned16 && t0 >= MfmaGeom<KS>::Tp && t0 + kMfmaTile <= c.rs.n_valid;
+}
+
+// vector v <-> input samples t0 - Tp + 4v .. + 3
+template <int KS>
+__device__ __forceinline__ void mfma_issue_loads(const MfmaTileCtx &c, uint64_t tile, uint32_t tid,
+                                                 uint4 (&q)[MfmaGeom<KS>::rounds]) {
+    using Gm = MfmaGeom<KS>;
+    const gbytes src4 = uniform_ptr((gbytes)(c.rs.src + (tile * kMfmaTile - Gm::Tp)));
+#pragma unroll
+    for (int i = 0; i < Gm::rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        // (a partial last round: the lanes past the window read its last vector again -- same cache line,
+        //  harmless to the min / max of the quiet test, never stored; a branch here would need its own address)
+        q[i] = ld_nt4_at(src4, 16u * ((64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? v : Gm::nvec - 1u));
+    }
+}
+
+// first / last tiles of a capture, halo of a shard, unaligned pointers: sample by sample, staged raw
+// through the (free) LDS window so that the code stays a compact loop
+template <int KS>
+__device__ __noinline__ void mfma_boundary_stage(RawSrc rs, uint64_t t0, uint32_t tid, uint4 *stage) {
+    using Gm = MfmaGeom<KS>;
+    for (uint32_t v = tid; v < Gm::nvec; v += 64u) {
+        const int64_t s0 = (int64_t)t0 - (int64_t)Gm::Tp + 4 * (int64_t)v;
+        uint4 w;
+        w.x = fetch_raw_m(rs, s0);
+        w.y = fetch_raw_m(rs, s0 + 1);
+        w.z = fetch_raw_m(rs, s0 + 2);
+        w.w = fetch_raw_m(rs, s0 + 3);
+        stage[v] = w;
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void mfma_boundary_loads(const MfmaTileCtx &c, uint64_t tile, uint32_t tid, unsigned char *win,
+                                                    uint4 (&q)[MfmaGeom<KS>::rounds]) {
+    using Gm = MfmaGeom<KS>;
+    uint4 *stage = reinterpret_cast<uint4 *>(win);
+    mfma_boundary_stage<KS>(c.rs, tile * kMfmaTile, tid, stage);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < Gm::rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        q[i] = stage[(64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? v : Gm::nvec - 1u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// raw window -> fp16 planes in LDS (masked: a wide tile's upper / lower bits)
+template <int KS>
+__device__ __forceinline__ void mfma_convert(const uint4 (&q)[MfmaGeom<KS>::rounds], uint32_t mask, uint32_t tid,
+                                             _Float16 *pl_re, _Float16 *pl_im) {
+    using Gm = MfmaGeom<KS>;
+#pragma unroll
+    for (int i = 0; i < Gm::rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        if (64u * (i + 1) <= Gm::nvec || v < Gm::nvec) {
+            h4 r4, i4;
+            cvt4(q[i], mask, r4, i4);
+            *reinterpret_cast<h4 *>(pl_re + mslot(4u * v)) = r4;
+            *reinterpret_cast<h4 *>(pl_im + mslot(4u * v)) = i4;
+        }
+    }
+    // the window is private to this wavefront and the LDS executes one wave's accesses in
+    // order: no workgroup barrier, only keep the compiler from moving reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// the K-steps over the planes; FIRST: the accumulators start from zero (the instruction's own C = 0).
+// One fragment set (16 registers) read per step -- the other waves of the SIMD cover the LDS latency; the
+// scheduling barriers keep the compiler from hoisting every step's reads to the front (64 registers with 32
+// taps, and then the raw window of the NEXT tile, in flight, is what gets spilled: a wait in front of the product).
+template <int KS, bool FIRST>
+__device__ __forceinline__ void mfma_ksteps(const h8 *a_img, const _Float16 *pl_re, const _Float16 *pl_im, uint32_t tid,
+                                            f16x &are, f16x &aim) {
+    const uint32_t n = tid & 31u, hh = tid >> 5;
+    const _Float16 *bre = pl_re + 40u * n + 8u * hh;
+    const _Float16 *bim = pl_im + 40u * n + 8u * hh;
+    const h8 *af = a_img + tid;
+    f16x zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const h8 xr = *reinterpret_cast<const h8 *>(bre + 16 * s + 8 * (s >> 1));
+        const h8 xi = *reinterpret_cast<const h8 *>(bim + 16 * s + 8 * (s >> 1));
+        const h8 a0 = af[(s * 2 + 0) * 64];
+        const h8 a1 = af[(s * 2 + 1) * 64];
+        are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xr, (FIRST && s == 0) ? zero : are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xi, (FIRST && s == 0) ? zero : aim, 0, 0, 0);
+        are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xr, are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xi, aim, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the next pass / tile rewrites the window: the reads above are done (the LDS is in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the A-fragment image -> LDS (idempotent; four fragments per turn in flight, not unrolled further: every
+// unrolled load would keep a hoisted 64-bit address pair alive across the whole tile loop)
+template <int KS>
+__device__ __noinline__ void mfma_fetch_image(const void *image, unsigned char *smem, uint32_t tid) {
+    v4u *dst = reinterpret_cast<v4u *>(smem) + tid;
+    const gptr128 src = reinterpret_cast<gptr128>((gbytes)image) + tid;
+    for (int i = 0; i < 2 * KS; i += 4) {
+        const v4u f0 = src[64 * i], f1 = src[64 * i + 64], f2 = src[64 * i + 128], f3 = src[64 * i + 192];
+        dst[64 * i] = f0;
+        dst[64 * i + 64] = f1;
+        dst[64 * i + 128] = f2;
+        dst[64 * i + 192] = f3;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(64 * kMfmaWaves) __attribute__((amdgpu_waves_per_eu(4)))
 void fir1_mfma_kernel(const FrontParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Gm = MfmaGeom<KS>;
-    constexpr uint32_t Tp = Gm::Tp;
     constexpr uint32_t kImgBytes = (uint32_t)KS * 2u * 1024u;
-    uint32_t tid = threadIdx.x & 63u;       // (re-derived every tile: see the loop head)
+    uint32_t tid = threadIdx.x & 63u;       // (made opaque once per tile: see the loop head)
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t n = tid & 31u, hh = tid >> 5;
     const uint32_t cap = blockIdx.y;
-    RawSrc rs;
-    rs.src = (gptr32)(reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride);
-    rs.halo = (gptr32)reinterpret_cast<const uint32_t *>(p.halo);
-    rs.halo_len = p.halo_len;
-    rs.n_valid = p.n_valid;
-    const gptr32 src = rs.src;
+    MfmaTileCtx c;
+    c.rs.src = (gptr32)(reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride);
+    c.rs.halo = (gptr32)reinterpret_cast<const uint32_t *>(p.halo);
+    c.rs.halo_len = p.halo_len;
+    c.rs.n_valid = p.n_valid;
+    c.ctl = reinterpret_cast<uint32_t *>(smem_raw + kImgBytes);
+    c.tickets = p.mfma_g;
+    c.tile_base = p.tile_base;
+    c.tile_end = p.tile_end;
+    c.aligned16 = (((uintptr_t)c.rs.src & 15u) == 0);
     typedef __attribute__((address_space(1))) uint64_t *gptr64;
     typedef __attribute__((address_space(1))) uint32_t *gptr32w;
     const gptr64 words = (gptr64)(p.bits + (uint64_t)cap * p.words_per_cap);
     const gptr32w tile_info = (gptr32w)(p.tile_info + (uint64_t)cap * p.tiles_per_cap);
     const h8 *a_img = reinterpret_cast<const h8 *>(smem_raw);
-    uint32_t *ctl = reinterpret_cast<uint32_t *>(smem_raw + kImgBytes);      // [0] next tile of the chunk, [1] image ready
     unsigned char *win = smem_raw + kImgBytes + kMfmaCtlBytes + wave * Gm::lds_bytes;
     _Float16 *pl_re = reinterpret_cast<_Float16 *>(win);
     _Float16 *pl_im = pl_re + Gm::plane;
-    const bool aligned16 = (((uintptr_t)src & 15u) == 0);
-    typedef float v2fm __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) v2fm *gptrf2;
     const gptrf2 fout = p.fir_out ? (gptrf2)(reinterpret_cast<v2fm *>(p.fir_out) + (uint64_t)cap * p.n_out) : (gptrf2)nullptr;
 
     if (threadIdx.x == 0) {
-        ctl[0] = 0;
-        ctl[1] = 0;
+        c.ctl[0] = 0;
+        c.ctl[1] = 0;
     }
     __syncthreads();
 
-    // ticket k of workgroup b is tile k * gridDim + b: the workgroups that are resident together (consecutive b,
-    // at about the same k) read one dense, moving window of the capture, like a hardware-dispatched grid of
-    // one-tile workgroups does.
-    // Software pipeline: the raw window of the NEXT tile is requested as soon as this tile's has arrived,
-    // before any of this tile's work -- a wave always has a window in flight.  (Anything that puts a second
-    // dependent memory round trip in front of those loads -- a register spilled to scratch and reloaded in
-    // the loop head, a ticket in global memory -- costs a whole loaded-memory latency per tile: measured
-    // 4.3 us per tile and wave instead of 1.7.)
-    auto take_ticket = [&](uint64_t &tile) -> bool {
-        uint32_t tk = 0;
-        if (tid == 0) tk = __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-        tile = (uint64_t)tk * gridDim.x + blockIdx.x + p.tile_base;
-        return tk < p.mfma_g && tile < p.tile_end;
-    };
-    auto is_interior = [&](uint64_t tile) -> bool {
-        const uint64_t t0 = tile * kMfmaTile;
-        return aligned16 && t0 >= Tp && t0 + kMfmaTile <= p.n_valid;
-    };
-    // vector v <-> input samples t0 - Tp + 4v .. + 3
-    auto issue_loads = [&](uint64_t tile, uint4 (&q)[Gm::rounds]) {
-        const gbytes src4 = uniform_ptr((gbytes)(src + (tile * kMfmaTile - Tp)));
-#pragma unroll
-        for (int i = 0; i < Gm::rounds; ++i) {
-            const uint32_t v = tid + 64u * i;
-            // (a partial last round: the lanes past the window read its last vector again -- same cache line,
-            //  harmless to the min / max below, never stored; a branch here would need its own address)
-            q[i] = ld_nt4_at(src4, 16u * ((64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? v : Gm::nvec - 1u));
-        }
-    };
-    // first / last tiles of a capture, halo of a shard, unaligned pointers: sample by sample, staged raw
-    // through the (free) LDS window so that the code stays a compact loop
-    auto boundary_loads = [&](uint64_t tile, uint4 (&q)[Gm::rounds]) {
-        const uint64_t t0 = tile * kMfmaTile;
-        uint4 *stage = reinterpret_cast<uint4 *>(win);
-#pragma unroll 1
-        for (uint32_t v = tid; v < Gm::nvec; v += 64u) {
-            const int64_t s0 = (int64_t)t0 - (int64_t)Tp + 4 * (int64_t)v;
-            uint4 w;
-            w.x = fetch_raw_m(rs, s0);
-            w.y = fetch_raw_m(rs, s0 + 1);
-            w.z = fetch_raw_m(rs, s0 + 2);
-            w.w = fetch_raw_m(rs, s0 + 3);
-            stage[v] = w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < Gm::rounds; ++i) {
-            const uint32_t v = tid + 64u * i;
-            q[i] = (64u * (i + 1) <= Gm::nvec || v < Gm::nvec) ? stage[v] : make_uint4(0, 0, 0, 0);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    // raw window -> fp16 planes in LDS (masked: a wide tile's upper / lower bits), then the K-steps
-    auto product = [&](const uint4 (&q)[Gm::rounds], uint32_t mask, f16x &are, f16x &aim) {
-#pragma unroll
-        for (int i = 0; i < Gm::rounds; ++i) {
-            const uint32_t v = tid + 64u * i;
-            if (64u * (i + 1) <= Gm::nvec || v < Gm::nvec) {
-                h4 r4, i4;
-                cvt4(q[i], mask, r4, i4);
-                *reinterpret_cast<h4 *>(pl_re + mslot(4u * v)) = r4;
-                *reinterpret_cast<h4 *>(pl_im + mslot(4u * v)) = i4;
-            }
-        }
-        // the window is private to this wavefront and the LDS executes one wave's accesses in
-        // order: no workgroup barrier, only keep the compiler from moving reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const _Float16 *bre = pl_re + 40u * n + 8u * hh;
-        const _Float16 *bim = pl_im + 40u * n + 8u * hh;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const h8 xr = *reinterpret_cast<const h8 *>(bre + 16 * s + 8 * (s >> 1));
-            const h8 xi = *reinterpret_cast<const h8 *>(bim + 16 * s + 8 * (s >> 1));
-            const h8 a0 = a_img[(s * 2 + 0) * 64 + tid];
-            const h8 a1 = a_img[(s * 2 + 1) * 64 + tid];
-            are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xr, are, 0, 0, 0);
-            aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xi, aim, 0, 0, 0);
-            are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xr, are, 0, 0, 0);
-            aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xi, aim, 0, 0, 0);
-        }
-        // the next pass / tile rewrites the window: the reads above are done (the LDS is in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
+    // thresholds in accumulator units: y = c z with c a power of two, so fl(y^2) = c^2 fl(z^2) and the
+    // comparisons below are the comparisons of the powers against the band, bit for bit
+    const float inv_c2 = 1.0f / (p.mfma_c * p.mfma_c);
 
     uint64_t tile = 0;
-    if (!take_ticket(tile)) return;
+    if (!mfma_take_ticket(c, tid, tile)) return;
     uint4 q[Gm::rounds];
-    if (is_interior(tile)) issue_loads(tile, q);
-    else boundary_loads(tile, q);
+    if (mfma_interior<KS>(c, tile)) mfma_issue_loads<KS>(c, tile, tid, q);
+    else mfma_boundary_loads<KS>(c, tile, tid, win, q);
     for (;;) {
         // Everything per lane below is a function of the lane id; left alone the compiler computes a dozen
         // offsets and addresses from it ONCE, keeps them alive across the whole loop and, out of registers,
         // reloads them from scratch right in front of the loads.  Opaque lane id => recomputed per tile
         // (a handful of VALU instructions), one live register.
         asm volatile("" : "+v"(tid));
-        n = tid & 31u;
-        hh = tid >> 5;
+        const uint32_t n = tid & 31u, hh = tid >> 5;
         const uint64_t t0 = tile * kMfmaTile;
         // ---- quiet test (exact: kernels.hip) and range of the window ------------------------------
         v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
@@ -325,137 +388,135 @@ void fir1_mfma_kernel(const FrontParams p) {
         const bool quiet = (!fout && __ballot(loud) == 0) || (p.mfma_debug & 1u);
         const bool wide = __ballot(mx.x > 2047 || mx.y > 2047 || mn.x < -2048 || mn.y < -2048) != 0;
 
-        // ---- the next tile's window: in flight during everything below -----------------------------
         uint64_t tile_n = 0;
-        const bool more = take_ticket(tile_n);
-        const bool pre = PRE && more && is_interior(tile_n);
-        uint4 qn[Gm::rounds];
-#pragma unroll
-        for (int i = 0; i < Gm::rounds; ++i) qn[i] = make_uint4(0, 0, 0, 0);
-        if (pre) issue_loads(tile_n, qn);
-
+        bool more = false, pre = false;
         if (quiet) {
+            more = mfma_take_ticket(c, tid, tile_n);
+            pre = more && mfma_interior<KS>(c, tile_n);
+            if (pre) mfma_issue_loads<KS>(c, tile_n, tid, q);
             if (!p.sparse) {
                 if (tid < kMfmaTile / 64) *reinterpret_cast<gptr64>(uniform_ptr((gbytes_w)(words + (t0 >> 6))) + 8u * tid) = 0;
                 if (tid == 0) *uniform_ptr(tile_info + tile) = 0;
             }
             if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + ((blockIdx.x * kMfmaWaves + wave) % kQuietCounters), 1u);
         } else {
-            if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
-                // the A-fragment image -> LDS (see above: idempotent, flag behind this wave's own stores)
-                // (four fragments per turn in flight; not unrolled further: every unrolled load would keep a
-                //  hoisted 64-bit address pair alive across the whole tile loop)
-                v4u *dst = reinterpret_cast<v4u *>(smem_raw) + tid;
-                gbytes img = uniform_ptr((gbytes)p.mfma_a);
-#pragma unroll 1
-                for (int i = 0; i < 2 * KS; i += 4) {
-                    img = uniform_ptr(img);
-                    const gptr128 s4 = reinterpret_cast<gptr128>(img + 16u * tid);
-                    const v4u f0 = s4[0], f1 = s4[64], f2 = s4[128], f3 = s4[192];
-                    dst[0] = f0;
-                    dst[64] = f1;
-                    dst[128] = f2;
-                    dst[192] = f3;
-                    dst += 256;
-                    img += 4096;
-                }
+            if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+                mfma_fetch_image<KS>(p.mfma_a, smem_raw, tid);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (tid == 0) __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tid == 0) __hip_atomic_store(&c.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
             f16x are, aim;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                are[r] = 0.0f;
-                aim[r] = 0.0f;
-            }
             if (!wide) {
-                product(q, 0xffffffffu, are, aim);
+                mfma_convert<KS>(q, 0xffffffffu, tid, pl_re, pl_im);
+                more = mfma_take_ticket(c, tid, tile_n);
+                pre = more && mfma_interior<KS>(c, tile_n);
+                if (pre) mfma_issue_loads<KS>(c, tile_n, tid, q);
+                mfma_ksteps<KS, true>(a_img, pl_re, pl_im, tid, are, aim);
             } else {
                 // a sample beyond +-2048 somewhere in the window: upper bits, then the low five bits
-                product(q, 0xffe0ffe0u, are, aim);
-                product(q, 0x001f001fu, are, aim);
+                mfma_convert<KS>(q, 0xffe0ffe0u, tid, pl_re, pl_im);
+                mfma_ksteps<KS, true>(a_img, pl_re, pl_im, tid, are, aim);
+                mfma_convert<KS>(q, 0x001f001fu, tid, pl_re, pl_im);
+                more = mfma_take_ticket(c, tid, tile_n);
+                pre = more && mfma_interior<KS>(c, tile_n);
+                if (pre) mfma_issue_loads<KS>(c, tile_n, tid, q);
+                mfma_ksteps<KS, false>(a_img, pl_re, pl_im, tid, are, aim);
             }
 
-        // ---- power, threshold, guard band: register r of lane (n, hh) is output 32 n + row(r) ------
-        const float c = p.mfma_c;
-        const float plo = wide ? p.p_lo_w : p.p_lo_n;
-        const float phi = wide ? p.p_hi_w : p.p_hi_n;
-        const uint32_t ocol = 32u * n + 4u * hh;
-        uint32_t m16 = 0, u16 = 0;
+            // ---- power, threshold, guard band: register r of lane (n, hh) is output 32 n + row(r) ------
+            // Per pair of outputs: two packed squares and a packed add; per output: one compare per bound
+            // whose wave-wide result lands in an SGPR pair, the lane's own bit shifted into `m16` through the
+            // carry (r runs downwards so bit r ends at position r), the "inside the band" masks OR-ed on the
+            // scalar unit.
+            const float plo = (wide ? p.p_lo_w : p.p_lo_n) * inv_c2;
+            const float phi = (wide ? p.p_hi_w : p.p_hi_n) * inv_c2;
+            const uint32_t ocol = 32u * n + 4u * hh;
+            uint32_t m16 = 0;
+            uint64_t any_unsure = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float yr = are[r] * c, yi = aim[r] * c;
-            are[r] = yr;
-            aim[r] = yi;
-            const float rr = yr * yr, ii = yi * yi;
-            const float pw = rr + ii;
-            const bool hi = pw >= phi;
-            m16 |= (hi ? 1u : 0u) << r;
-            u16 |= ((!hi && pw >= plo) ? 1u : 0u) << r;
-        }
-        if (__ballot(u16 != 0) != 0) {
-            uint32_t todo = u16, redo = 0;
-            while (todo) {
-                const uint32_t r = (uint32_t)__ffs((int)todo) - 1u;
-                todo &= todo - 1u;
-                const uint64_t o = t0 + ocol + (r & 3u) + 8u * (r >> 2);
-                if (o >= p.n_out) continue;
-                const float2 y = mfma_exact_output(rs, (gptrf)p.taps, p.stage[0].ntaps, (int64_t)o);
-                const float rr = y.x * y.x, ii = y.y * y.y;
-                const float pe = rr + ii;
-                m16 = (m16 & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
-                redo++;
+            for (int r2 = 7; r2 >= 0; --r2) {
+                const v2fm zr = (v2fm){are[2 * r2], are[2 * r2 + 1]}, zi = (v2fm){aim[2 * r2], aim[2 * r2 + 1]};
+                const v2fm rr = zr * zr, ii = zi * zi;
+                const v2fm pw = rr + ii;
+                {
+                    const uint64_t ge_hi = __ballot(pw.y >= phi);
+                    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(m16) : "s"(ge_hi) : "vcc");
+                    any_unsure |= __ballot(pw.y >= plo) & ~ge_hi;
+                }
+                {
+                    const uint64_t ge_hi = __ballot(pw.x >= phi);
+                    asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(m16) : "s"(ge_hi) : "vcc");
+                    any_unsure |= __ballot(pw.x >= plo) & ~ge_hi;
+                }
             }
-            if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
-        }
-        if (fout) {
+            if (any_unsure != 0) {
+                // some lane of this wave has an output inside the band: those lanes redo their borderline
+                // outputs in the reference's exact order (from the capture itself)
+                uint32_t todo = 0, redo = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint64_t o = t0 + ocol + (r & 3) + 8 * (r >> 2);
-                if (o < p.n_out) fout[o] = (v2fm){are[r], aim[r]};
+                for (int r = 0; r < 16; ++r) {
+                    const float rr = are[r] * are[r], ii = aim[r] * aim[r];
+                    const float pw = rr + ii;
+                    if (pw >= plo && !(pw >= phi)) todo |= 1u << r;
+                }
+                while (todo) {
+                    const uint32_t r = (uint32_t)__ffs((int)todo) - 1u;
+                    todo &= todo - 1u;
+                    const uint64_t o = t0 + ocol + (r & 3u) + 8u * (r >> 2);
+                    if (o >= p.n_out) continue;
+                    const float2 y = mfma_exact_output(c.rs, (gptrf)p.taps, p.stage[0].ntaps, (int64_t)o);
+                    const float rr = y.x * y.x, ii = y.y * y.y;
+                    const float pe = rr + ii;
+                    m16 = (m16 & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
+                    redo++;
+                }
+                if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
             }
-        }
+            if (fout) {
+                const float cs = p.mfma_c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t o = t0 + ocol + (r & 3) + 8 * (r >> 2);
+                    if (o < p.n_out) fout[o] = (v2fm){are[r] * cs, aim[r] * cs};
+                }
+            }
 
-        // ---- 32 bits per column: rows (r & 3) + 8 (r >> 2) + 4 hh ---------------------------------
-        uint32_t m32 = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
-        m32 <<= 4u * hh;
-        uint32_t w32 = m32 | (uint32_t)__shfl_xor((int)m32, 32);
-        {
-            // outputs past the end of the (padded) capture do not exist
-            const uint64_t c0 = t0 + 32u * n;
-            if (c0 + 32u > p.n_out) {
-                const uint32_t keep = c0 >= p.n_out ? 0u : (uint32_t)(p.n_out - c0);
-                w32 &= (1u << keep) - 1u;       // keep < 32 here
+            // ---- 32 bits per column: rows (r & 3) + 8 (r >> 2) + 4 hh ---------------------------------
+            uint32_t m32 = (m16 & 0xfu) | ((m16 & 0xf0u) << 4) | ((m16 & 0xf00u) << 8) | ((m16 & 0xf000u) << 12);
+            m32 <<= 4u * hh;
+            uint32_t w32 = m32 | (uint32_t)__shfl_xor((int)m32, 32);
+            {
+                // outputs past the end of the (padded) capture do not exist
+                const uint64_t c0 = t0 + 32u * n;
+                if (c0 + 32u > p.n_out) {
+                    const uint32_t keep = c0 >= p.n_out ? 0u : (uint32_t)(p.n_out - c0);
+                    w32 &= (1u << keep) - 1u;       // keep < 32 here
+                }
             }
-        }
-        // level changes inside the tile (the tile's first bit against the tile before NOT included)
-        {
-            const uint32_t prev_top = (uint32_t)__shfl_up((int)(w32 >> 31), 1);
-            uint32_t ch = w32 ^ (w32 << 1);
-            if (n != 0) ch ^= prev_top & 1u;
-            else ch &= ~1u;
-            uint32_t cnt = hh == 0 ? (uint32_t)__popc(ch) : 0u;
+            // level changes inside the tile (the tile's first bit against the tile before NOT included)
+            {
+                const uint32_t prev_top = (uint32_t)__shfl_up((int)(w32 >> 31), 1);
+                uint32_t ch = w32 ^ (w32 << 1);
+                if (n != 0) ch ^= prev_top & 1u;
+                else ch &= ~1u;
+                uint32_t cnt = hh == 0 ? (uint32_t)__popc(ch) : 0u;
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
-            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w32 & 1u));
-            const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(w32 >> 31), 31);
-            if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
-        }
-        const uint32_t up = (uint32_t)__shfl_xor((int)w32, 1);
-        if (hh == 0 && (n & 1u) == 0) {
-            const gbytes_w wb = uniform_ptr((gbytes_w)(words + (t0 >> 6)));
-            *reinterpret_cast<gptr64>(wb + 4u * n) = (uint64_t)w32 | ((uint64_t)up << 32);
-        }
+                for (int d = 16; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w32 & 1u));
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(w32 >> 31), 31);
+                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+            }
+            const uint32_t up = (uint32_t)__shfl_xor((int)w32, 1);
+            if (hh == 0 && (n & 1u) == 0) {
+                const gbytes_w wb = uniform_ptr((gbytes_w)(words + (t0 >> 6)));
+                *reinterpret_cast<gptr64>(wb + 4u * n) = (uint64_t)w32 | ((uint64_t)up << 32);
+            }
         }   // loud tile
 
         if (!more) break;
-        if (!pre) {
-            if (is_interior(tile_n)) issue_loads(tile_n, qn);
-            else boundary_loads(tile_n, qn);
-        }
-#pragma unroll
-        for (int i = 0; i < Gm::rounds; ++i) q[i] = qn[i];
+        if (!pre) mfma_boundary_loads<KS>(c, tile_n, tid, win, q);       // (the LDS window is free: every read of it is done)
         tile = tile_n;
     }
 }
@@ -561,8 +622,7 @@ bool front_uses_mfma(const FrontParams &p) {
 template <int KS>
 static hipError_t launch_mfma_ks(FrontParams &pp, uint32_t num_captures, uint64_t grid, hipStream_t stream,
                                  hipEvent_t t0, hipEvent_t t1) {
-    const void *fn = (pp.mfma_debug & 2u) ? reinterpret_cast<const void *>(&fir1_mfma_kernel<KS, false>)
-                                          : reinterpret_cast<const void *>(&fir1_mfma_kernel<KS, true>);
+    const void *fn = reinterpret_cast<const void *>(&fir1_mfma_kernel<KS>);
     const size_t lds = mfma_lds_bytes<KS>();
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
