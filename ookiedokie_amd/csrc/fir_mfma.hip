@@ -155,7 +155,7 @@ __device__ __forceinline__ void cvt4(uint4 q, uint32_t mask, h4 &re, h4 &im) {
 }
 
 // Workgroup = kMfmaWaves wavefronts that share ONE copy of the A-fragment image in LDS (8 KB with 32
-// taps, 36 KB with 255) and otherwise work alone: each wave pulls tiles (FrontParams::mfma_g per workgroup)
+// taps, 36 KB with 255) and otherwise work alone: each wave pulls tiles (FrontParams::mfma_g per wave)
 // from a ticket in LDS, so a wave that drew loud tiles does not hold the others up, and a quiet tile costs
 // nothing but its loads.  The image is fetched by the first wave that meets a loud tile (another wave
 // doing the same at the same time stores the same bytes); the ready flag is set behind that wave's own
@@ -174,12 +174,17 @@ __device__ __forceinline__ void cvt4(uint4 q, uint32_t mask, h4 &re, h4 &im) {
 // tile and wave instead of 1.7.)
 //
 // Registers (96: five waves per SIMD): 32 accumulators + two A / B fragment sets + the raw window.
-constexpr int kMfmaWaves = 4;
+// Waves per workgroup: as many as it takes to have 16 waves per CU beside ONE image per workgroup in the
+// 160 KB of LDS -- 4 up to 64 taps (image 8 / 12 KB), 8 up to 128 (20 KB), 16 up to 256 (36 KB: one
+// workgroup per CU; with four waves per workgroup only two workgroups fit, two waves per SIMD, and the
+// matrix pipe idles while both convert or threshold: measured 41 % MFMA + 33 % VALU busy, hardly overlapping).
+template <int KS>
+__host__ __device__ constexpr int mfma_waves() { return KS <= 6 ? 4 : KS <= 10 ? 8 : 16; }
 constexpr uint32_t kMfmaCtlBytes = 16;
 
 template <int KS>
 __host__ __device__ constexpr uint32_t mfma_lds_bytes() {
-    return (uint32_t)KS * 2u * 1024u + kMfmaCtlBytes + (uint32_t)kMfmaWaves * MfmaGeom<KS>::lds_bytes;
+    return (uint32_t)KS * 2u * 1024u + kMfmaCtlBytes + (uint32_t)mfma_waves<KS>() * MfmaGeom<KS>::lds_bytes;
 }
 
 struct MfmaTileCtx {            // uniform per workgroup
@@ -276,9 +281,9 @@ __device__ __forceinline__ void mfma_convert(const uint4 (&q)[MfmaGeom<KS>::roun
 }
 
 // the K-steps over the planes; FIRST: the accumulators start from zero (the instruction's own C = 0).
-// One fragment set (16 registers) read per step -- the other waves of the SIMD cover the LDS latency; the
-// scheduling barriers keep the compiler from hoisting every step's reads to the front (64 registers with 32
-// taps, and then the raw window of the NEXT tile, in flight, is what gets spilled: a wait in front of the product).
+// Two fragment sets: step s + 1 is read while step s multiplies; the scheduling barriers keep the compiler
+// from hoisting every step's reads to the front (64 registers with 32 taps -- and then the raw window of
+// the NEXT tile, in flight, is what gets spilled: a wait in front of the product).
 template <int KS, bool FIRST>
 __device__ __forceinline__ void mfma_ksteps(const h8 *a_img, const _Float16 *pl_re, const _Float16 *pl_im, uint32_t tid,
                                             f16x &are, f16x &aim) {
@@ -289,17 +294,26 @@ __device__ __forceinline__ void mfma_ksteps(const h8 *a_img, const _Float16 *pl_
     f16x zero;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+    h8 xr = *reinterpret_cast<const h8 *>(bre), xi = *reinterpret_cast<const h8 *>(bim);
+    h8 a0 = af[0], a1 = af[64];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const h8 xr = *reinterpret_cast<const h8 *>(bre + 16 * s + 8 * (s >> 1));
-        const h8 xi = *reinterpret_cast<const h8 *>(bim + 16 * s + 8 * (s >> 1));
-        const h8 a0 = af[(s * 2 + 0) * 64];
-        const h8 a1 = af[(s * 2 + 1) * 64];
+        h8 xr_n = xr, xi_n = xi, a0_n = a0, a1_n = a1;
+        if (s + 1 < KS) {
+            xr_n = *reinterpret_cast<const h8 *>(bre + 16 * (s + 1) + 8 * ((s + 1) >> 1));
+            xi_n = *reinterpret_cast<const h8 *>(bim + 16 * (s + 1) + 8 * ((s + 1) >> 1));
+            a0_n = af[((s + 1) * 2 + 0) * 64];
+            a1_n = af[((s + 1) * 2 + 1) * 64];
+        }
         are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xr, (FIRST && s == 0) ? zero : are, 0, 0, 0);
         aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xi, (FIRST && s == 0) ? zero : aim, 0, 0, 0);
         are = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xr, are, 0, 0, 0);
         aim = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xi, aim, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        xr = xr_n;
+        xi = xi_n;
+        a0 = a0_n;
+        a1 = a1_n;
     }
     // the next pass / tile rewrites the window: the reads above are done (the LDS is in order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -322,8 +336,9 @@ __device__ __noinline__ void mfma_fetch_image(const void *image, unsigned char *
 }
 
 template <int KS>
-__global__ __launch_bounds__(64 * kMfmaWaves) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(64 * mfma_waves<KS>()) __attribute__((amdgpu_waves_per_eu(4)))
 void fir1_mfma_kernel(const FrontParams p) {
+    constexpr int kMfmaWaves = mfma_waves<KS>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using Gm = MfmaGeom<KS>;
     constexpr uint32_t kImgBytes = (uint32_t)KS * 2u * 1024u;
@@ -336,7 +351,7 @@ void fir1_mfma_kernel(const FrontParams p) {
     c.rs.halo_len = p.halo_len;
     c.rs.n_valid = p.n_valid;
     c.ctl = reinterpret_cast<uint32_t *>(smem_raw + kImgBytes);
-    c.tickets = p.mfma_g;
+    c.tickets = p.mfma_g * (uint32_t)kMfmaWaves;
     c.tile_base = p.tile_base;
     c.tile_end = p.tile_end;
     c.aligned16 = (((uintptr_t)c.rs.src & 15u) == 0);
@@ -627,7 +642,7 @@ static hipError_t launch_mfma_ks(FrontParams &pp, uint32_t num_captures, uint64_
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     void *args[] = {&pp};
-    e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kMfmaWaves), args, lds, stream, t0, t1, 0);
+    e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * mfma_waves<KS>()), args, lds, stream, t0, t1, 0);
     return e != hipSuccess ? e : hipGetLastError();
 }
 
@@ -642,12 +657,13 @@ hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStr
     pp.tile_base = (uint32_t)b;
     pp.tile_end = b + cnt;
     if (pp.mfma_g == 0) pp.mfma_g = 1;
-    const uint64_t grid = (cnt + pp.mfma_g - 1) / pp.mfma_g;
+    // pp.mfma_g = tickets per wave; a workgroup of W waves hands out W times as many
+    auto grid_for = [&](int waves) { return (cnt + (uint64_t)pp.mfma_g * waves - 1) / ((uint64_t)pp.mfma_g * waves); };
     switch (mfma_ksteps_for(p.stage[0].ntaps)) {
-    case 4: return launch_mfma_ks<4>(pp, num_captures, grid, stream, t0, t1);
-    case 6: return launch_mfma_ks<6>(pp, num_captures, grid, stream, t0, t1);
-    case 10: return launch_mfma_ks<10>(pp, num_captures, grid, stream, t0, t1);
-    case 18: return launch_mfma_ks<18>(pp, num_captures, grid, stream, t0, t1);
+    case 4: return launch_mfma_ks<4>(pp, num_captures, grid_for(mfma_waves<4>()), stream, t0, t1);
+    case 6: return launch_mfma_ks<6>(pp, num_captures, grid_for(mfma_waves<6>()), stream, t0, t1);
+    case 10: return launch_mfma_ks<10>(pp, num_captures, grid_for(mfma_waves<10>()), stream, t0, t1);
+    case 18: return launch_mfma_ks<18>(pp, num_captures, grid_for(mfma_waves<18>()), stream, t0, t1);
     default: return hipErrorInvalidValue;
     }
 }

@@ -72,7 +72,7 @@ struct FrontParams {
     float mfma_c;               // accumulator * mfma_c = filter output
     float p_lo_n, p_hi_n;       // guard band of a tile whose samples all lie within +-2048 (one sample piece)
     float p_lo_w, p_hi_w;       // ... of a tile with samples beyond (two sample pieces)
-    uint32_t mfma_g;            // consecutive wave tiles per workgroup (the A fragments are loaded once for them)
+    uint32_t mfma_g;            // wave tiles (tickets) per wave of a workgroup (the A-fragment image is fetched once for them)
     uint64_t tile_end;          // first wave tile past this launch (set by launch_front_mfma)
     uint32_t mfma_debug;        // experiments (OOKD_MFMA_DEBUG): bit 0 = every tile takes the quiet exit (timing only)
 };

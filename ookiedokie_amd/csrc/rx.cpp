@@ -1435,7 +1435,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rx->mfma_c = mt.c;
             band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, false), rx->p_star, rx->p_lo_n, rx->p_hi_n);
             band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, true), rx->p_star, rx->p_lo_w, rx->p_hi_w);
-            rx->mfma_g = 16;        // wave tiles per (4-wave) workgroup
+            // wave tiles per wave of a workgroup: more for the long filters, whose workgroups fill a CU and
+            // fetch a 20 / 36 KB image each (config2 sweep: 474 / 545 / 599 / 623 / 635 Gsamples/s at 2 / 4 / 8 / 16 / 32)
+            rx->mfma_g = mt.ksteps <= 6 ? 4u : mt.ksteps <= 10 ? 16u : 32u;
             if (const char *g = getenv("OOKD_MFMA_G")) rx->mfma_g = (uint32_t)std::min(4096, std::max(1, atoi(g)));
         }
     }

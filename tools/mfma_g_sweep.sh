@@ -1,7 +1,7 @@
 #!/bin/bash
 # sweep of FrontParams::mfma_g (wave tiles per workgroup of the matrix-core front end)
 mkdir -p gpurun_out/r03
-for g in ${@:-4 8 16 32 64}; do
+for g in ${@:-2 4 8 16}; do
   OOKD_MFMA_G=$g timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03/sweep_g$g.json 2> gpurun_out/r03/sweep_g$g.err || exit 1
   python - <<PY
 import json
