@@ -201,6 +201,57 @@ def main():
     nctx = max(1, args.contexts)
     out = None
 
+    def front_kernel_name(filt, exact=False, quiet=True):
+        """the kernel the library launches for this filter (csrc/kernels.hip: launch_front)"""
+        if filt is None:
+            return "nofir_bits_kernel (unpack+threshold+bitpack)"
+        if filt.total_decimation == 1 and filt.num_stages == 1 and not exact and not os.environ.get("OOKD_FIR_VALU"):
+            return "fir1_mfma_kernel (unpack + split-fp16 Toeplitz FIR on the matrix cores + threshold + bitpack)"
+        if filt.num_stages == 1:
+            return "fir1_bits_kernel (unpack+FIR+threshold+bitpack)"
+        if filt.num_stages == 2:
+            return "fir2_bits_kernel (unpack + two decimating FIR stages + threshold + bitpack)"
+        return "fir_generic_kernel"
+
+    def sub_record(what, filt, device, ptrs_, n_, ncaps_=1, stride_=None, contexts=(3, 1), steps=10, flop_per_sample=None,
+                   **rkw):
+        """One more workload through the same timed loop (its own contexts, its own short warm-up):
+        ms per step with `contexts[0]` captures in flight and strictly one after the other."""
+        stride_ = stride_ or n_
+        rec = {"what": what}
+        g2 = ok.FrontGate()
+        mk = lambda: ok.Receiver(filt, device, max_samples=n_, max_captures=ncaps_, threshold=THRESHOLD,
+                                 samples_per_buffer=SPB, hip_device=local_rank, front_gate=g2, **rkw)
+        for nc in contexts:
+            rr = [mk() for _ in range(nc)]
+            hh = [r._h for r in rr]
+            pp = [C.c_void_p(ptrs_[i % len(ptrs_)]) for i in range(nc)]
+            last = None
+            for i in range(max(3, nc)):
+                last = rr[i % nc].rx_device(ptrs_[i % len(ptrs_)], n_, num_captures=ncaps_, stride=stride_)
+            e, f, d, nl = timed_steps(hh, pp, ncaps_, n_, stride_, steps)
+            kms = float(np.mean(f))
+            dec_ = filt.total_decimation if filt else 1
+            bps = 4.0 + 0.125 / dec_
+            key = "contexts_%d" % nc
+            rec[key] = {"ms_per_step": round(e / steps * 1e3, 4),
+                        "value": round(float(n_) * ncaps_ * steps / e / 1e6, 1), "unit": "Msamples/s",
+                        "frac_of_hbm_read_roofline": round(float(n_) * ncaps_ * steps / e / 1e6 / (HBM_PEAK_GBS * 1e3 / 4.0), 4),
+                        "kernel_ms": round(kms, 4),
+                        "kernel_frac_of_hbm_peak": round(bps * n_ * ncaps_ / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "front_launches": nl}
+            if flop_per_sample:
+                rec[key]["fir_tflops"] = round(flop_per_sample * n_ * ncaps_ / (kms * 1e-3) / 1e12, 2)
+            rec["messages_per_step"] = int(len(last.msg_samples))
+            rec["edges_per_step"] = int(last.stats["num_edges"])
+            rec["fsm_path"] = int(last.stats["fsm_path"])
+            rec["guard_recomputes"] = int(last.stats["guard_recomputes"])
+            for r in rr:
+                r.close()
+        g2.close()
+        rec["kernel"] = front_kernel_name(filt)
+        return rec
+
     # =====================================================================================================
     if args.workload == "sharded":
         # configs[4]: one capture cut into WORLD_SIZE contiguous shards, halo + carried state exchanged
@@ -334,6 +385,51 @@ def main():
                         "fix_point_rounds": int(frx.stats()["fsm_iterations"])}
             frx.close()
             srx.close()
+        configs = None
+        if (rank == 0 and world == 1 and not args.no_sub_records and args.workload == "capture" and n == N_SAMPLES
+                and args.filter == "fs32_fs4" and not args.no_quiet_skip and not args.exact):
+            # ---- the other single-GPU configurations of BASELINE.json, each through the same timed loop --------
+            configs = {}
+            p0 = [b.data_ptr() for b in bufs]
+            configs["config1"] = sub_record(
+                "configs[1]: 1 GiB synthetic SC16Q11 capture (268435456 samples), fs32_fs4 FIR, p3l-nexa2012, 1 MI355X",
+                flt, dev, p0, 1 << 28, flop_per_sample=FIR_FLOP_PER_SAMPLE)
+            configs["dec4"] = sub_record(
+                "backend default filter fs128_fs16_dec4 (16 taps / 2, 32 taps / 2: SURVEY.md 8(f) row f1), 16 GiB capture, p3l-nexa2012",
+                ok.Filter.load(golden("filters", "fs128_fs16_dec4")), ok.Device.load(golden("devices", "p3l-nexa2012"), RATE // 4),
+                p0, n, contexts=(3,), steps=8)
+            # configs[2]: 255 real taps = float32(hamming-windowed sinc, cutoff Fs/64, unity DC gain), unknown-remote1
+            import tempfile
+            kk = np.arange(255) - 127
+            hh = np.sinc(kk / 32.0) * np.hamming(255)
+            hh = hh / hh.sum()
+            tdir = tempfile.mkdtemp()
+            with open(os.path.join(tdir, "sinc255.json"), "w") as f:
+                json.dump({"filter": {"stages": [{"decimation": 1, "taps": list(hh)}]}}, f)
+            f255 = ok.Filter.load(os.path.join(tdir, "sinc255.json"))
+            dev2 = ok.Device.load(golden("devices", "unknown-remote1"), RATE)
+            syn2 = ok.Synth(dev2, n, seed=SEED_BASE + 3, sample_rate=RATE)
+            cap2 = torch.empty(2 * n + 64, dtype=torch.int16, device="cuda")
+            syn2.fill_device(cap2.data_ptr(), hip_device=local_rank)
+            torch.cuda.synchronize()
+            configs["config2"] = sub_record(
+                "configs[2]: 16 GiB synthetic SC16Q11 capture (4294967296 samples), 255-tap synthetic FIR (hamming-windowed "
+                "sinc, cutoff Fs/64), unknown-remote1 decoder, 1 MI355X; the contexts share one resident capture",
+                f255, dev2, [cap2.data_ptr()], n, contexts=(3, 1), steps=6, flop_per_sample=1020.0)
+            del cap2
+            # configs[3], one GPU's share: 128 captures of 2^24 samples per batched call
+            bstride = BATCH_SAMPLES + 64
+            bbuf = torch.empty(2 * bstride * BATCH_CAPTURES + 64, dtype=torch.int16, device="cuda")
+            for i in range(BATCH_CAPTURES):
+                sb = ok.Synth(dev, BATCH_SAMPLES, seed=SEED_BASE + 1000 + i, sample_rate=RATE)
+                sb.fill_device(bbuf.data_ptr() + 4 * bstride * i, hip_device=local_rank)
+            torch.cuda.synchronize()
+            configs["batch"] = sub_record(
+                "configs[3], one GPU's share: %d independent captures of %d samples (64 MiB) in ONE batched call per step, "
+                "fs32_fs4 FIR, p3l-nexa2012; the contexts share one resident batch" % (BATCH_CAPTURES, BATCH_SAMPLES),
+                flt, dev, [bbuf.data_ptr()], BATCH_SAMPLES, ncaps_=BATCH_CAPTURES, stride_=bstride, contexts=(3,), steps=8,
+                flop_per_sample=FIR_FLOP_PER_SAMPLE, message_capacity=1 << 18)
+            del bbuf
         if rank == 0:
             total_samples = float(n) * ncaps * args.steps * world
             value = total_samples / elapsed / 1e6
@@ -375,7 +471,7 @@ def main():
                     "workload": wl,
                     "samples_per_capture": n, "captures_per_step": ncaps, "filter": args.filter,
                     "device": "p3l-nexa2012", "sample_rate": RATE, "threshold": THRESHOLD,
-                    "samples_per_buffer": SPB, "fir_mode": "exact" if args.exact else "fma+guard-band",
+                    "samples_per_buffer": SPB, "fir_mode": "exact" if args.exact else "fp16-split MFMA, exact products + guard band (bits exact)",
                     "parallelism": "independent captures per rank, no collective",
                     "backend": backend or "none",
                     "messages_per_step": int(len(res.msg_samples)),
@@ -391,13 +487,15 @@ def main():
                     # the front end of a step goes out as `launches_per_step` grid launches of the same
                     # kernel; the library times first start -> last end (HIP events riding on the
                     # dispatches), so one launch lasts that / launches and moves bytes / launches
-                    "kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack)",
+                    "kernel": front_kernel_name(flt, args.exact),
                     "bound": "hbm",
                     "achieved": round(achieved_gbs, 1),
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                     "traffic": traffic,
+                    "traffic_note": "PMC bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) of a --contexts 1 run, per launch: "
+                                    "profiles/traffic.json; the time above is with %d contexts in flight" % nctx,
                     "launches_per_step": nlaunch,
                     "avg_kernel_ms": round(fir_avg_ms / nlaunch, 4),
                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * n * ncaps / nlaunch,
@@ -413,6 +511,7 @@ def main():
                 "single_context": single,
                 "worst_case": worst,
                 "fallback_path": fallback,
+                "configs": configs,
             }
 
         # ---- CPU baseline: the oracle on this host's cores (rank 0, N = 1 only) -------------
