@@ -372,9 +372,6 @@ void fir1_mfma_kernel(const FrontParams p) {
     }
     __syncthreads();
 
-    // thresholds in accumulator units: y = c z with c a power of two, so fl(y^2) = c^2 fl(z^2) and the
-    // comparisons below are the comparisons of the powers against the band, bit for bit
-    const float inv_c2 = 1.0f / (p.mfma_c * p.mfma_c);
 
     uint64_t tile = 0;
     if (!mfma_take_ticket(c, tid, tile)) return;
@@ -445,8 +442,11 @@ void fir1_mfma_kernel(const FrontParams p) {
             // whose wave-wide result lands in an SGPR pair, the lane's own bit shifted into `m16` through the
             // carry (r runs downwards so bit r ends at position r), the "inside the band" masks OR-ed on the
             // scalar unit.
-            const float plo = (wide ? p.p_lo_w : p.p_lo_n) * inv_c2;
-            const float phi = (wide ? p.p_hi_w : p.p_hi_n) * inv_c2;
+            // (the bands arrive in accumulator units: y = c z with c a power of two, so fl(y^2) = c^2 fl(z^2) and
+            //  these comparisons are the comparisons of the powers against the band, bit for bit; the host only
+            //  takes this path when the scaling of the band edges is exact: mfma_scale_band)
+            const float plo = wide ? p.p_lo_w : p.p_lo_n;
+            const float phi = wide ? p.p_hi_w : p.p_hi_n;
             const uint32_t ocol = 32u * n + 4u * hh;
             uint32_t m16 = 0;
             uint64_t any_unsure = 0;
@@ -627,6 +627,22 @@ double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide) {
     const double e_ref = ((double)ntaps + 1.0) * u * t.sum_abs;
     const double e_acc = chain * 2.0 * u * t.sum_hat;
     return 1.1 * (e_ref + e_acc + t.delta) * xmax + (double)ntaps * std::ldexp(1.0, -140);
+}
+
+// band edge (a power, filter output units) -> accumulator units: p / c^2.  False when that is not exact in
+// float (the caller then keeps the packed-VALU form)
+bool mfma_scale_band(const MfmaTaps &t, float p, float &out) {
+    if (std::isnan(p) || std::isinf(p) || p == 0.0f) {
+        out = p;
+        return true;
+    }
+    int e = 0;
+    (void)std::frexp((double)t.c, &e);          // c = 2^(e-1)
+    const double scaled = std::ldexp((double)p, -2 * (e - 1));
+    const float f = (float)scaled;
+    if (!std::isfinite(f) || (double)f != scaled || std::fabs(f) < 1.1754944e-38f) return false;
+    out = f;
+    return true;
 }
 
 bool front_uses_mfma(const FrontParams &p) {

@@ -1211,8 +1211,9 @@ hipError_t ensure_dynamic_lds(const void *func, size_t bytes) {
 }
 
 static bool use_fir1(const FrontParams &p) {
+    // (the tuned kernels' load rounds cover a tap history of up to 256 samples; longer filters: generic kernel)
     return p.num_stages == 1 && p.stage[0].decim == 1 && p.origin == 0 && !p.iq_f32 &&
-           fir1_lds_bytes(p) <= 160 * 1024;
+           p.stage[0].ntaps_pad <= 256u && fir1_lds_bytes(p) <= 160 * 1024;
 }
 
 static bool use_fir2(const FrontParams &p) {

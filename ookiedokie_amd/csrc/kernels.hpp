@@ -70,7 +70,8 @@ struct FrontParams {
     // matrix-core form of the 1-stage kernel (fir_mfma.hip); mfma_a == null: packed-VALU form
     const void *mfma_a;         // A-fragment image of the split taps (mfma_prepare_taps)
     float mfma_c;               // accumulator * mfma_c = filter output
-    float p_lo_n, p_hi_n;       // guard band of a tile whose samples all lie within +-2048 (one sample piece)
+    float p_lo_n, p_hi_n;       // guard band of a tile whose samples all lie within +-2048 (one sample piece),
+                                // in ACCUMULATOR units (power / mfma_c^2: mfma_scale_band)
     float p_lo_w, p_hi_w;       // ... of a tile with samples beyond (two sample pieces)
     uint32_t mfma_g;            // wave tiles (tickets) per wave of a workgroup (the A-fragment image is fetched once for them)
     uint64_t tile_end;          // first wave tile past this launch (set by launch_front_mfma)
@@ -130,6 +131,8 @@ struct MfmaTaps {
 bool mfma_prepare_taps(const float *taps, uint32_t ntaps, MfmaTaps &out);
 // forward bound on |y_mfma - y_ref| per component (filter output units)
 double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide);
+// a band edge in accumulator units (p / c^2); false when the scaling is not exact in float
+bool mfma_scale_band(const MfmaTaps &t, float p, float &out);
 bool front_uses_mfma(const FrontParams &p);
 hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
                              hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count);

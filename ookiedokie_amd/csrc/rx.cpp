@@ -1423,9 +1423,21 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         // 1 stage, decimation 1, <= 256 taps: the product runs on the matrix cores (fir_mfma.hip) unless the
         // caller asks for the packed-VALU loop (or for the experimental streaming form, which only exists for it)
         MfmaTaps mt;
+        bool use_mfma = false;
         if (rx->num_stages == 1 && rx->stage[0].decim == 1 && !(cfg->flags & OOKD_RX_FIR_VALU) &&
             !getenv("OOKD_FRONT_STREAM") && !getenv("OOKD_FIR_VALU") &&
             mfma_prepare_taps(filter->stages[0].taps.data(), rx->stage[0].ntaps, mt)) {
+            float lo_n, hi_n, lo_w, hi_w;
+            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, false), rx->p_star, lo_n, hi_n);
+            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, true), rx->p_star, lo_w, hi_w);
+            // the kernel compares in accumulator units; thresholds so far from the filter's range that the
+            // power-of-two scaling leaves the normal floats stay on the packed-VALU loop
+            use_mfma = mfma_scale_band(mt, lo_n, rx->p_lo_n) && mfma_scale_band(mt, hi_n, rx->p_hi_n) &&
+                       mfma_scale_band(mt, lo_w, rx->p_lo_w) && mfma_scale_band(mt, hi_w, rx->p_hi_w);
+            // fl(y^2) = c^2 fl(z^2) needs y^2 clear of the subnormals (and of overflow) wherever it decides a bit
+            if (rx->p_star > 0.0f && !(rx->p_star >= 0x1p-100f && rx->p_star <= 0x1p100f)) use_mfma = false;
+        }
+        if (use_mfma) {
             if (rx->d_mfma_a.alloc(mt.image.size()) != OOKD_OK) return nullptr;
             if (hipMemcpy(rx->d_mfma_a.p, mt.image.data(), mt.image.size() * sizeof(uint16_t),
                           hipMemcpyHostToDevice) != hipSuccess) {
@@ -1433,8 +1445,6 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 return nullptr;
             }
             rx->mfma_c = mt.c;
-            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, false), rx->p_star, rx->p_lo_n, rx->p_hi_n);
-            band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, true), rx->p_star, rx->p_lo_w, rx->p_hi_w);
             // wave tiles per wave of a workgroup: more for the long filters, whose workgroups fill a CU and
             // fetch a 20 / 36 KB image each (config2 sweep: 474 / 545 / 599 / 623 / 635 Gsamples/s at 2 / 4 / 8 / 16 / 32)
             rx->mfma_g = mt.ksteps <= 6 ? 4u : mt.ksteps <= 10 ? 16u : 32u;

@@ -339,6 +339,120 @@ def test_dense_random_levels(ok, oracle, filt, n):
         rx.close()
 
 
+# ------------------------------------------ matrix-core form of the 1-stage front end ----
+
+def _write_filter(tmp_path, taps, name):
+    p = tmp_path / (name + ".json")
+    p.write_text(json.dumps({"filter": {"stages": [{"decimation": 1, "taps": [float(t) for t in taps]}]}}))
+    return str(p)
+
+
+def _loud_capture(n, rng, wide):
+    """every window loud, the filtered magnitude crossing the threshold all the time; `wide`: samples over
+    the whole int16 range (the matrix-core form splits those into two fp16 pieces)"""
+    t = np.arange(n)
+    env = 205.0 * (1.0 + 0.8 * np.sin(2 * np.pi * t / 3000.0)) * (12.0 if wide else 1.0)
+    ph = rng.uniform(0, 2 * np.pi)
+    amp = 2500 if wide else 250
+    i = env * np.cos(ph) + rng.integers(-amp, amp + 1, size=n)
+    q = env * np.sin(ph) + rng.integers(-amp, amp + 1, size=n)
+    if wide:
+        idx = rng.integers(0, n, size=n // 40)
+        i[idx] = rng.choice([-32768, 32767, -2049, 2048, -2048, 2047], size=idx.size)
+        q[idx[::2]] = rng.choice([-32768, 32767], size=idx[::2].size)
+    lim = 32767 if wide else 2047
+    iq = np.empty(2 * n, dtype=np.int16)
+    iq[0::2] = np.clip(np.round(i), -lim - 1, lim).astype(np.int16)
+    iq[1::2] = np.clip(np.round(q), -lim - 1, lim).astype(np.int16)
+    return iq
+
+
+@pytest.mark.parametrize("ntaps", [1, 2, 31, 32, 33, 64, 65, 128, 129, 255, 256, 257])
+def test_mfma_fir_tap_counts(ok, oracle, tmp_path, ntaps):
+    """Single-stage filters of every compiled window length (and one beyond, which stays on the packed-VALU
+    kernel): bits of the matrix-core form == oracle == packed-VALU form; floats within the stated tolerance;
+    nominal and wide sample ranges; capture lengths that end inside a tile."""
+    rng = np.random.default_rng(1000 + ntaps)
+    taps = rng.normal(0, 1, ntaps) * np.hamming(ntaps + 2)[1:-1]
+    taps = (taps / np.abs(taps).sum() * 1.7).astype(np.float32)
+    path = _write_filter(tmp_path, taps, "t%d" % ntaps)
+    f = ok.Filter.load(path)
+    of = oracle.load_filter_json(path)
+    for wide, n in ((False, 70000 + ntaps), (True, 33000)):
+        iq = _loud_capture(n, rng, wide)
+        y0 = oracle.rx(iq, of, 0.0, None, 8192, want_bits=True, want_fir=True).fir.astype(np.float64)
+        thr = float(np.float32(np.median(np.sqrt(y0[:, 0] ** 2 + y0[:, 1] ** 2))))        # in the middle of the output range
+        want = oracle.rx(iq, of, thr, None, 8192, want_bits=True, want_fir=True)
+        assert 0.2 < want.bits.mean() < 0.8
+        scale = float(np.abs(taps).sum()) * float(np.abs(iq.astype(np.int32)).max()) / 2048.0
+        for valu in (False, True):
+            rx = ok.Receiver(f, None, max_samples=n, threshold=thr, edge_capacity=n + 64, keep_fir=True, fir_valu=valu)
+            rx.rx(iq)
+            assert (rx.bits() == want.bits).all(), (ntaps, wide, valu)
+            assert list(rx.edges()) == list(edges_of(want.bits))
+            y = rx.fir_output()
+            assert (np.abs(y - want.fir) <= FIR_RTOL * np.maximum(np.abs(want.fir), scale)).all(), (ntaps, wide, valu)
+            rx.close()
+            # and without the float output (quiet shortcut armed, sparse words)
+            rx = ok.Receiver(f, None, max_samples=n, threshold=thr, edge_capacity=n + 64, fir_valu=valu)
+            rx.rx(iq)
+            assert (rx.bits() == want.bits).all(), (ntaps, wide, valu)
+            rx.close()
+
+
+@pytest.mark.parametrize("scale", [1e-15, 1e-6, 1e-3, 1.0, 37.5, 1e6, 1e15])
+def test_mfma_fir_tap_magnitudes(ok, oracle, tmp_path, scale):
+    """Taps of any magnitude and dynamic range (a tap 2^-30 of the largest still counts; filters the
+    matrix-core form refuses fall back to the packed-VALU loop): bits == oracle with a threshold placed
+    in the middle of the output range."""
+    rng = np.random.default_rng(77)
+    ntaps = 48
+    taps = rng.normal(0, 1, ntaps)
+    taps[5] *= 2.0 ** -30
+    taps[17] = 0.0
+    taps = (taps / np.abs(taps).sum() * scale).astype(np.float32)
+    path = _write_filter(tmp_path, taps, "m")
+    f = ok.Filter.load(path)
+    of = oracle.load_filter_json(path)
+    n = 50000
+    iq = _loud_capture(n, rng, False)
+    y = oracle.rx(iq, of, 0.0, None, 8192, want_bits=True, want_fir=True).fir
+    mag = np.sqrt(y[:, 0].astype(np.float64) ** 2 + y[:, 1].astype(np.float64) ** 2)
+    thr = float(np.float32(np.median(mag)))
+    if not np.isfinite(thr) or thr <= 0.0:
+        pytest.skip("degenerate output range")
+    want = oracle.rx(iq, of, thr, None, 8192, want_bits=True)
+    assert 0.2 < want.bits.mean() < 0.8
+    rx = ok.Receiver(f, None, max_samples=n, threshold=thr, edge_capacity=n + 64)
+    rx.rx(iq)
+    assert (rx.bits() == want.bits).all()
+    rx.close()
+
+
+def test_mfma_guard_band_forces_exact_recompute_255_taps(ok, oracle, tmp_path):
+    """the 255-tap filter with the filtered magnitude hovering around the threshold: every borderline output
+    goes through the reference-order recompute (from the capture itself) and the bits are the oracle's"""
+    k = np.arange(255) - 127
+    h = np.sinc(k / 32.0) * np.hamming(255)
+    h = (h / h.sum()).astype(np.float32)
+    path = _write_filter(tmp_path, h, "sinc255")
+    f = ok.Filter.load(path)
+    of = oracle.load_filter_json(path)
+    rng = np.random.default_rng(19)
+    n = 300000
+    base = 204.7 + 0.6 * np.sin(np.arange(n) / 7000.0)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.round(base + rng.normal(0, 3.0, n)).astype(np.int16)
+    iq[1::2] = rng.integers(-2, 3, n).astype(np.int16)
+    rx = ok.Receiver(f, None, max_samples=n, edge_capacity=n + 1024)
+    got = rx.rx(iq)
+    want = oracle.rx(iq, of, 0.1, None, 8192, want_bits=True)
+    assert (rx.bits() == want.bits).all()
+    assert got.stats["guard_recomputes"] > 20
+    assert 0.05 < want.bits.mean() < 0.95
+    rx.close()
+
+
 # ------------------------------------------------------------- guard band ----
 
 @pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
