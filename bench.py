@@ -70,15 +70,16 @@ def spawn_ranks(args):
     process has touched a GPU (device_count() does not initialise one)."""
     import torch
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
-        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report fewer ranks than asked for"
+    if ndev < args.gpus and not args.allow_shared_gpu:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report fewer ranks than asked for "
+                         "(--allow-shared-gpu: rehearse the multi-rank path with ranks sharing a GPU, gloo)"
                          % (args.gpus, ndev))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(1, ndev)), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -106,6 +107,8 @@ def main():
     ap.add_argument("--no-quiet-skip", action="store_true",
                     help="filter every window, even those provably below the threshold (worst case)")
     ap.add_argument("--backend", default="", help="torch.distributed backend (default: nccl = RCCL; gloo when ranks share a GPU)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="rehearsal: let --gpus N start N ranks on a box with fewer GPUs (the line says so; never a scaling number)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,7 +259,7 @@ def main():
     if args.workload == "sharded":
         # configs[4]: one capture cut into WORLD_SIZE contiguous shards, halo + carried state exchanged
         from ookiedokie_amd.distributed import demodulate_sharded
-        n = args.samples or (1 << 32)               # per shard (configs[4]: 32 GiB per GPU; 16 GiB keeps a lease short)
+        n = args.samples or (1 << 33)               # per shard: configs[4] = 256 GiB over 8 GPUs = 2^33 samples (32 GiB) each
         total = n * world
         syn = ok.Synth(dev, total, seed=SEED_BASE + 5, sample_rate=RATE)
         shard = torch.empty(2 * n + 64, dtype=torch.int16, device="cuda")
@@ -283,6 +286,42 @@ def main():
             res = one_step()
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        # ---- checker (untimed): the shards' messages, gathered in capture order, against the whole capture --------
+        allmsgs = res
+        if dist is not None:
+            from ookiedokie_amd.distributed import gather_messages
+            allmsgs = gather_messages(res)
+        check = {}
+        if rank == 0:
+            ms = np.asarray(allmsgs.msg_samples, dtype=np.uint64)
+            pays = np.asarray(allmsgs.payloads)
+            check["messages"] = int(ms.size)
+            check["messages_in_increasing_order"] = bool((np.diff(ms.astype(np.int64)) > 0).all()) if ms.size > 1 else True
+            check["last_message_sample"] = int(ms[-1]) if ms.size else 0
+            free, _ = torch.cuda.mem_get_info()
+            if world > 1 and 4 * total + (2 << 30) < free and total <= (1 << 32):
+                # the whole capture fits beside the shard: decode it in one piece and compare
+                whole = torch.empty(2 * total + 64, dtype=torch.int16, device="cuda")
+                syn.fill_device(whole.data_ptr(), hip_device=local_rank)
+                wrx = ok.Receiver(flt, dev, max_samples=total, threshold=THRESHOLD, samples_per_buffer=SPB, hip_device=local_rank)
+                wres = wrx.rx_device(whole.data_ptr(), total)
+                check["sharded_equals_whole"] = bool(list(wres.msg_samples) == [int(x) for x in ms]
+                                                     and (np.asarray(wres.payloads) == pays).all())
+                wrx.close()
+                del whole
+            else:
+                # too large for one GPU: every decoded payload was transmitted, in transmission order, and nearly all were
+                sent = [syn.message(i)[1] for i in range(syn.num_messages)]
+                j, okk = 0, True
+                for pl in pays:
+                    while j < len(sent) and sent[j] != bytes(pl):
+                        j += 1
+                    if j >= len(sent):
+                        okk = False
+                        break
+                    j += 1
+                check["sharded_equals_whole"] = None
+                check["decoded_are_sent_in_order"] = bool(okk and len(pays) >= 0.8 * (len(sent) - 2))
         if rank == 0:
             st = rx.stats()
             out = {
@@ -296,8 +335,10 @@ def main():
                            "samples_per_shard": n, "shards": world, "halo_samples": H, "filter": args.filter,
                            "device": "p3l-nexa2012", "backend": backend or "none",
                            "state_exchange_rounds": int(getattr(res, "rounds", 0)),
-                           "parallelism": "contiguous shards, neighbour halo send/recv + all-gather of a 64-byte state"},
-                "roofline": {"kernel": "fir1_bits_kernel (unpack+FIR+threshold+bitpack)", "bound": "hbm",
+                           "rehearsal_ranks_share_a_gpu": bool(shared_gpu),
+                           "parallelism": "contiguous shards, neighbour halo send/recv + all-gather of a 64-byte state",
+                           **check},
+                "roofline": {"kernel": front_kernel_name(flt, args.exact), "bound": "hbm",
                              "achieved": round(BYTES_PER_SAMPLE * n / (st["fir_kernel_ms"] * 1e-3) / 1e9, 1),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(BYTES_PER_SAMPLE * n / (st["fir_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -135,33 +135,41 @@ def demodulate_sharded(engine, *, d_iq_ptr: int, num_local_samples: int, tail_sa
                 send_t = torch.cat([before, own.to(before.device)])[-2 * H:] if own is not None else before
                 dist.send(send_t.contiguous(), dst=peer(rank + 1), group=group)
         halo = recv_t
+        if halo is not None and getattr(halo, "is_cuda", False):
+            # With nccl / RCCL `wait()` and `recv` only order torch's CURRENT stream behind the communication
+            # stream; they neither block the host nor say anything to the receiver's own (non-blocking) HIP
+            # stream, on which shard_begin copies the halo and runs the front end.  The halo must have landed
+            # before that stream may read it.
+            torch.cuda.current_stream(halo.device).synchronize()
 
     # ---- 2. speculative pass ----------------------------------------------------------
     result, out = engine.shard_begin(d_iq_ptr, num_local_samples, halo, rank == world - 1, None)
 
     # ---- 3. carried-state fix-point ------------------------------------------------------
+    # ONE collective per round: every rank sees every shard's outgoing state, so "nothing changed
+    # anywhere" is a comparison of this round's gathered states with the last round's (on the
+    # communication device) -- no second collective for a flag.  Only the predecessor's 64 bytes come
+    # to the host, and only when they differ from what this shard was run with.
     my_in: Optional[bytes] = None
+    prev_all = None
     rounds = 0
-    for _ in range(max_rounds):
+    for _ in range(max_rounds + 1):
         mine = _to_tensor(bytes(out), comm_device)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)
-        changed = 0
+        all_states = torch.stack(gathered)
+        if prev_all is not None:
+            if torch.equal(all_states, prev_all):
+                break               # every shard ran with its predecessor's final outgoing state
+            rounds += 1
+        prev_all = all_states
         if rank > 0:
             want = bytes(gathered[rank - 1].cpu().numpy().tobytes())
             if want != my_in:
                 # (the first round always lands here: the speculative pass
                 #  assumed a state, now it learns the predecessor's)
                 my_in = want
-                before = bytes(out)
                 result, out = engine.shard_refine(engine.state_from_bytes(want))
-                changed = int(bytes(out) != before)
-        flag = torch.tensor([changed], dtype=torch.int32,
-                            device=comm_device if comm_device is not None else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        if int(flag.item()) == 0:
-            break
-        rounds += 1
     else:
         raise RuntimeError("carried-state exchange did not converge")
 

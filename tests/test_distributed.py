@@ -190,7 +190,7 @@ def test_partition_and_bounds():
 
 # ----------------------------------------------------------------------------- GPU
 
-def _gpu_worker(rank, world, port, out_q):
+def _gpu_worker(rank, world, port, out_q, device_tail=False):
     import torch
     import torch.distributed as dist
     import ookiedokie_amd as ok
@@ -212,8 +212,17 @@ def _gpu_worker(rank, world, port, out_q):
     lo, hi = bounds[rank], bounds[rank + 1]
     t = torch.from_numpy(iq[2 * lo:2 * hi].copy()).cuda()
     rx = ok.Receiver(flt, dev, max_samples=hi - lo, samples_per_buffer=8192)
-    res = okd.demodulate_sharded(rx, d_iq_ptr=t.data_ptr(), num_local_samples=hi - lo,
-                                 tail_samples=iq[2 * lo:2 * hi], decimated_offset=lo // flt.total_decimation)
+    if device_tail:
+        # the nccl / RCCL shape of the call on one GPU: tail and received halo are DEVICE tensors (gloo moves
+        # them through the host underneath, but shard_begin gets a device pointer it copies on its own stream)
+        H = int(rx.halo_samples)
+        tail = t[2 * (hi - lo - H):] if H else t[:0]
+        res = okd.demodulate_sharded(rx, d_iq_ptr=t.data_ptr(), num_local_samples=hi - lo, tail_samples=tail,
+                                     decimated_offset=lo // flt.total_decimation,
+                                     comm_device=torch.device("cuda", 0))
+    else:
+        res = okd.demodulate_sharded(rx, d_iq_ptr=t.data_ptr(), num_local_samples=hi - lo,
+                                     tail_samples=iq[2 * lo:2 * hi], decimated_offset=lo // flt.total_decimation)
     allres = okd.gather_messages(res)
     if rank == 0:
         out_q.put((allres.msg_samples.tolist(), [bytes(p).hex() for p in allres.payloads]))
@@ -222,12 +231,13 @@ def _gpu_worker(rank, world, port, out_q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_one_capture_matches_oracle(oracle, vectors):
+@pytest.mark.parametrize("device_tail", [False, True])
+def test_two_ranks_one_capture_matches_oracle(oracle, vectors, device_tail):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q, device_tail)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -243,3 +253,48 @@ def test_two_ranks_one_capture_matches_oracle(oracle, vectors):
     want = oracle.rx(iq, of, 0.1, od, 8192)
     assert got[0] == [int(s) for s in want.msg_samples] and len(got[0]) == 3
     assert got[1] == [bytes(p).hex() for p in want.payloads]
+
+
+# ------------------------------------------------- bench.py --gpus 2 as fresh child processes
+
+def _bench_line(args, timeout=600):
+    """python bench.py <args> in a fresh process (nothing in it has touched a GPU when it spawns its ranks)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharded_on_one_gpu():
+    """`bench.py --gpus 2 --workload sharded`: two ranks (gloo: they share this box's GPU) cut ONE capture in two,
+    exchange halo + carried state, and the line's own check says the sharded result equals the whole capture's."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("rehearsal of the two-rank path on ONE device")
+    d = _bench_line(["--gpus", "2", "--workload", "sharded", "--backend", "gloo", "--samples", "16777216",
+                     "--steps", "2", "--warmup", "1", "--allow-shared-gpu"])
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "gloo" and d["config"]["shards"] == 2
+    assert d["config"]["samples_per_shard"] == 16777216
+    assert d["config"]["sharded_equals_whole"] is True and d["config"]["messages"] > 0
+    assert d["scaling"] == "weak" and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_batch_on_one_gpu():
+    """`bench.py --gpus 2 --workload batch`: independent captures per rank, no data-path collective"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("rehearsal of the two-rank path on ONE device")
+    d = _bench_line(["--gpus", "2", "--workload", "batch", "--backend", "gloo", "--samples", "1048576",
+                     "--steps", "2", "--warmup", "1", "--contexts", "1", "--no-sub-records", "--allow-shared-gpu"])
+    assert d["n_gpus"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["captures_per_step"] == 128 and d["config"]["messages_per_step"] >= 0
+    assert d["value"] > 0

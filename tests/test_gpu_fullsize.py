@@ -162,3 +162,37 @@ def test_config4_8GiB_as_two_shards_equals_whole(ok):
     assert (np.concatenate([r0.payloads, r1.payloads]) == whole.payloads).all()
     rx.close()
     rx1.close()
+
+
+def test_config4_shard_size_32GiB_whole_equals_two_shards(ok):
+    """configs[4]'s per-GPU shard size: a 2^33-sample (32 GiB) capture decoded whole -- message indices and the
+    front end's tile / word arithmetic beyond 2^32 -- and as two shards of 2^32 with halo + carried state"""
+    _need(110)
+    from ookiedokie_amd.distributed import shard_bounds
+    n = 1 << 33
+    flt = ok.Filter.load(golden_path("filters", "fs32_fs4"))
+    dev = ok.Device.load(golden_path("devices", "p3l-nexa2012"), RATE)
+    cap, syn = _capture(ok, dev, n, 0xC5)
+    rx = ok.Receiver(flt, dev, max_samples=n)
+    whole = rx.rx_device(cap.data_ptr(), n)
+    assert whole.stats["decimated_samples"] == n and whole.stats["fsm_path"] == 1
+    decoded = _sent_in_order(syn, whole)
+    assert decoded > 15000
+    ms = whole.msg_samples.astype(np.int64)
+    assert (np.diff(ms) > 0).all() and int(ms[-1]) > (1 << 33) - (1 << 22)
+    assert int((ms > (1 << 32)).sum()) > 7000           # plenty of messages beyond the 32-bit range
+    rx.close()
+    b = shard_bounds(n, 2, 8192, flt.total_decimation)
+    rx0 = ok.Receiver(flt, dev, max_samples=b[1])
+    H = rx0.halo_samples
+    r0, s0 = rx0.shard_begin(cap.data_ptr(), b[1], None, False, None)
+    halo = cap[2 * (b[1] - H):2 * b[1]]
+    rx1 = ok.Receiver(flt, dev, max_samples=n - b[1])
+    r1, s1 = rx1.shard_begin(cap.data_ptr() + 4 * b[1], n - b[1], halo, True, None)
+    if bytes(s0) != bytes(ok.FsmState()):
+        r1, s1 = rx1.shard_refine(s0)
+    got = list(r0.msg_samples) + [int(x) + b[1] // flt.total_decimation for x in r1.msg_samples]
+    assert got == [int(x) for x in whole.msg_samples], "sharded != whole"
+    assert (np.concatenate([r0.payloads, r1.payloads]) == whole.payloads).all()
+    rx0.close()
+    rx1.close()
