@@ -502,7 +502,7 @@ struct ScanParams {
     uint32_t leaf_block;        // leaves per block (<= 256)
     uint32_t *fin_off;          // [captures + 1] prefix of finish-block counts
     unsigned long long *fagg;   // [finish blocks][4, two used] appends | outputs << 20, errors | (last epoch start + 1) << 12; each | stamp << 32
-    uint32_t *fin_ticket;       // next finish block to hand out (zero at launch)
+    unsigned long long *fin_ticket;     // next finish block to hand out: count | run stamp << 32 (take_stamped_ticket)
     uint32_t run_stamp;         // != 0, different from the previous launch's
     uint32_t fin_blocks_cap;
     // span tables (build_leaf_tables): packed result of a span as a function of its
@@ -2323,6 +2323,25 @@ __device__ __forceinline__ uint32_t agg_load(const unsigned long long *slot, uin
     }
 }
 
+// A work counter that needs no zeroing between launches: count | run stamp << 32.  Whoever finds another
+// run's stamp in it swaps in  0 | this run's stamp  (one of the finders wins, the others see the new stamp
+// and carry on); counts are only ever added to a word that carries the current stamp.  Tickets 0, 1, 2, ...
+// are handed out exactly once per launch whatever the word held before -- nothing depends on a memset
+// having been ordered in front of the kernel, or on its visibility.
+__device__ __forceinline__ uint32_t take_stamped_ticket(unsigned long long *w, uint32_t stamp) {
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 32) != stamp) {
+            unsigned long long expect = v;
+            (void)__hip_atomic_compare_exchange_strong(w, &expect, (unsigned long long)stamp << 32, __ATOMIC_RELAXED,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const unsigned long long old = __hip_atomic_fetch_add(w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(old >> 32) == stamp) return (uint32_t)old;
+    }
+}
+
 __device__ __forceinline__ uint64_t pool_start(uint64_t e0, uint32_t cap) {
     return 2 * (e0 + cap) + (uint64_t)cap * 512;    // 2 per leaf + 512 per capture
 }
@@ -2342,7 +2361,7 @@ __global__ __launch_bounds__(kFinBlock) void fin_write_kernel(ScanParams sp) {
     const uint32_t tid = threadIdx.x;
     for (;;) {
         if (tid == 0) {
-            s_g = atomicAdd(sp.fin_ticket, 1u);
+            s_g = take_stamped_ticket(sp.fin_ticket, stamp);
             s_acc[0] = s_acc[1] = s_acc[2] = s_acc[3] = 0;
         }
         __syncthreads();

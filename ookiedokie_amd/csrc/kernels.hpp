@@ -351,7 +351,7 @@ struct FsmScanArgs {
     uint32_t *fallback;         // device word: non-zero => result invalid, use the round path
     uint32_t *fin_off;          // [captures + 1]
     void *fsum;                 // [fin_blocks_cap] x 32 B: stamped block aggregates
-    uint32_t *fin_ticket;       // zero at launch
+    unsigned long long *fin_ticket;     // the finish kernel's work counter: count | run stamp << 32, never zeroed
     uint32_t run_stamp;         // != 0, changes every launch
     uint32_t fin_blocks_cap;
     uint32_t *cap_group_off;    // [captures + 1]

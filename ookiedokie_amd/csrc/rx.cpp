@@ -46,7 +46,7 @@ struct ResultHeader {
     unsigned long long recompute;
     uint32_t total_edges;
     uint32_t scan_fallback;
-    uint32_t fin_ticket;        // work counter of the scan's finish kernel
+    uint32_t reserved0;
     uint32_t publish_done;      // workgroups of the scan's publishing kernel that are through
 };
 
@@ -308,7 +308,8 @@ struct ookd_rx {
     std::vector<Chunk> chunks;      // of the last run (empty: not pipelined)
     DevBuf<SegState> d_carry;       // [2] state handed from chunk to chunk
     DevBuf<uint64_t> d_chunk_totals;    // [2][2] messages / errors so far
-    DevBuf<uint32_t> d_fin_tickets; // [kMaxChunks] the finish kernel's work counter, one per chunk
+    DevBuf<unsigned long long> d_fin_tickets;   // [kMaxChunks + 1] the finish kernel's stamped work counters: one per
+                                                // chunk of a pipelined run, the last one for whole runs
     const void *last_iq = nullptr;  // arguments of the last run (a refused pipelined run is redone whole)
     uint64_t last_stride = 0;
     bool no_pipeline_once = false;
@@ -708,7 +709,6 @@ int ookd_rx::run_pipelined(const void *d_iq) {
     }
     if (hdr_dirty) HIPCHK(hipMemsetAsync(d_hdr.p, 0, sizeof(ResultHeader), stream));
     hdr_dirty = true;
-    HIPCHK(hipMemsetAsync(d_fin_tickets.p, 0, sizeof(uint32_t) * nc, stream));
     FrontParams fp = front_params(d_iq, run_n_valid);
     {
         const int rc = prepare_front(fp);
@@ -1125,7 +1125,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.skipc = d_skipc.p;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
-    a.fin_ticket = &d_hdr.p->fin_ticket;
+    a.fin_ticket = d_fin_tickets.p + kMaxChunks;
     if (++scan_stamp == 0) scan_stamp = 1;
     a.run_stamp = scan_stamp;
     a.fin_blocks_cap = scan_fin_cap;
@@ -1661,6 +1661,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
             rc |= rx->d_fin_off.alloc(caps + 1);
             rc |= rx->d_fsum.alloc(4 * (size_t)rx->scan_fin_cap);
+            // stamped work counters (fsm_scan.hip: take_stamped_ticket): zeroed ONCE -- stamp 0 is no run's
+            rc |= rx->d_fin_tickets.alloc(kMaxChunks + 1);
+            if (rc == OOKD_OK && hipMemset(rx->d_fin_tickets.p, 0, (kMaxChunks + 1) * sizeof(unsigned long long)) != hipSuccess) rc = OOKD_ERR_HIP;
             // stamped aggregates: the stamp half of every word must start out as "no run"
             if (rc == OOKD_OK && hipMemset(rx->d_fsum.p, 0, rx->d_fsum.n * sizeof(uint64_t)) != hipSuccess) rc = OOKD_ERR_HIP;
         }
@@ -1742,8 +1745,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             set_error("creating the pipeline streams failed");
             return nullptr;
         }
-        if (rx->d_carry.alloc(2) != OOKD_OK || rx->d_chunk_totals.alloc(4) != OOKD_OK ||
-            rx->d_fin_tickets.alloc(kMaxChunks) != OOKD_OK) {
+        if (rx->d_carry.alloc(2) != OOKD_OK || rx->d_chunk_totals.alloc(4) != OOKD_OK) {
             return nullptr;
         }
     }
