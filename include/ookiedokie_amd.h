@@ -169,9 +169,11 @@ enum {
      * up in the per-device span tables built at create time (identical
      * results; exists so the tests can run both). */
     OOKD_RX_SCAN_SIMS = 1u << 5,
-    /* Front end: launch one workgroup per wave tile (the round-1 form) instead
-     * of the persistent streaming grid that pulls batches of tiles from ticket
-     * heads (identical bits; exists so the tests can run both). */
+    /* Front end, packed-VALU form: the hardware-dispatched grid of one-tile
+     * workgroups.  This IS the default; the flag only matters to a developer
+     * build that selected the experimental persistent streaming form
+     * (OOKD_DEVELOPER=1 OOKD_FRONT_STREAM=1), where it forces
+     * the grid form back (identical bits). */
     OOKD_RX_FRONT_GRID = 1u << 6,
     /* Never pipeline a long capture in chunks (see pipeline_chunk_samples). */
     OOKD_RX_NO_PIPELINE = 1u << 7,
@@ -337,6 +339,12 @@ int ookd_rx_get_edges(const ookd_rx *rx, uint32_t capture, uint64_t *edges,
                       uint64_t capacity, uint64_t *num_edges);
 int ookd_rx_get_fir(const ookd_rx *rx, uint32_t capture, ookd_complexf *out,
                     uint64_t capacity);
+/* errors: capture-local decimated indices of the samples on which the state
+ *         machine reported an error (device.c:646), in increasing order per
+ *         capture.  In a batched run the list is capture-major, EXCEPT when the
+ *         scan form refused some captures and those were redone by the round
+ *         form (stats.fsm_path 3): then the refused captures' errors follow
+ *         those of all the others.  *num is always the total. */
 int ookd_rx_get_errors(const ookd_rx *rx, uint64_t *samples, uint64_t capacity,
                        uint64_t *num);
 

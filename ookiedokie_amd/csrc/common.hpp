@@ -4,12 +4,21 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "../../include/ookiedokie_amd.h"
 
 namespace ookd {
+
+// Experiment / test hooks read from the environment only exist for a process that asks for
+// them with OOKD_DEVELOPER=1: a normal run of the library never changes behaviour because of a stray variable.
+// (OOKD_DEBUG* diagnostics print, they do not change results, and stay plain getenv.)
+inline const char *dev_getenv(const char *name) {
+    const char *d = std::getenv("OOKD_DEVELOPER");
+    return (d && d[0] && d[0] != '0') ? std::getenv(name) : nullptr;
+}
 
 // Thread-local "last error" text (the reference prints through log_error).
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));

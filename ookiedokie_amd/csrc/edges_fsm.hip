@@ -492,6 +492,121 @@ __device__ __forceinline__ LaneTables load_tables(const FsmTablesDev *g) {
     return t;
 }
 
+// ---- devices with more than 64 states / triggers: the same evaluation with the tables in LDS ----------
+// (kernels.hpp: kMaxStatesBig).  A state's triggers are looked at 64 at a time, lane l taking trigger
+// begin + 64 c + l: "first in file order" is the first set bit of the first chunk that has one.
+struct BigTab {
+    const uint32_t *st;         // [states][6]
+    const uint32_t *tr;         // [triggers][3]
+    uint32_t max_bits;
+};
+
+__device__ __forceinline__ bool big_cond(uint32_t cond, uint32_t kto, uint32_t k, uint32_t prev, uint32_t b,
+                                         uint32_t nbits, uint32_t max_bits) {
+    bool c = cond == kCondAlways;
+    c = c || (cond == kCondPulseStart && !prev && b);
+    c = c || (cond == kCondPulseEnd && prev && !b);
+    c = c || (cond == kCondTimeout && k >= kto);
+    c = c || (cond == kCondMsgComplete && nbits >= max_bits);
+    return c;
+}
+
+// index of the first trigger of state s that matches, or -1 (wave-uniform)
+__device__ __forceinline__ int big_match(const BigTab &t, uint32_t s, uint32_t k, uint32_t prev, uint32_t b, uint32_t nbits) {
+    const uint32_t *row = t.st + kBigStateWords * s;
+    const uint32_t kto = row[2], beg = row[3], end = row[4];
+    for (uint32_t base = beg; base < end; base += 64) {
+        const uint32_t i = base + lane_id();
+        bool m = false;
+        if (i < end) {
+            const uint32_t *tg = t.tr + kBigTrigWords * i;
+            m = k >= tg[0] && k <= tg[1] && big_cond(tg[2] & 0xffu, kto, k, prev, b, nbits, t.max_bits);
+        }
+        const uint64_t ball = __ballot(m);
+        if (ball) return (int)(base + (uint32_t)__builtin_ctzll(ball));
+    }
+    return -1;
+}
+
+// with the level constant: evaluations from now until a trigger of state s fires (kNone = never), wave-uniform
+__device__ __forceinline__ uint32_t big_wait(const BigTab &t, uint32_t s, uint32_t k, uint32_t nbits) {
+    const uint32_t *row = t.st + kBigStateWords * s;
+    const uint32_t kto = row[2], beg = row[3], end = row[4];
+    uint32_t best = kNone;
+    for (uint32_t base = beg; base < end; base += 64) {
+        const uint32_t i = base + lane_id();
+        uint32_t w = kNone;
+        if (i < end) {
+            const uint32_t *tg = t.tr + kBigTrigWords * i;
+            const uint32_t cond = tg[2] & 0xffu;
+            bool can = true;
+            uint32_t lo = tg[0];
+            if (cond == kCondTimeout) {
+                can = kto != kNone;
+                lo = lo > kto ? lo : kto;
+            } else if (cond == kCondMsgComplete) {
+                can = nbits >= t.max_bits;
+            } else {
+                can = cond == kCondAlways;
+            }
+            const uint32_t first = k > lo ? k : lo;
+            can = can && first <= tg[1] && first <= kSat;
+            w = can ? first - k : kNone;
+        }
+        const uint32_t m = wave_min(w);
+        best = m < best ? m : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ int big_fire(const BigTab &t, Fsm &f, uint32_t s, uint32_t fired) {
+    const uint32_t info = t.tr[kBigTrigWords * fired + 2];
+    const uint32_t fc = info & 0xffu, act = (info >> 8) & 0xffu, next = info >> 16;
+    int result = kResNone;
+    bool ok = true;
+    if (fc == kCondPulseStart || fc == kCondPulseEnd) {
+        ok = f.k >= t.st[kBigStateWords * s] && f.k <= t.st[kBigStateWords * s + 1];
+    }
+    if (ok) {
+        if (act == kActAppend0 || act == kActAppend1) {
+            if (f.nbits <= t.max_bits) set_bit(f, f.nbits, act == kActAppend1);
+            f.nbits += 1;
+        } else if (act == kActOutput) {
+            result = kResOutput;
+        }
+        f.cur = next;
+    } else {
+        result = kResError;
+        f.cur = 0;
+    }
+    f.k = 0;
+    return result;
+}
+
+__device__ __forceinline__ int big_eval(const BigTab &t, Fsm &f, uint32_t b) {
+    const uint32_t s = f.cur;
+    const int m = big_match(t, s, f.k, f.prev, b, f.nbits);
+    if (m < 0) {
+        f.k = sat_add(f.k, 1);
+        return kResNone;
+    }
+    return big_fire(t, f, s, (uint32_t)m);
+}
+
+__device__ __forceinline__ int big_step(const BigTab &t, Fsm &f, uint32_t b) {
+    if (f.cur == 0) {
+        f.nbits = 0;
+        f.d0 = f.d1 = f.d2 = f.d3 = f.d4 = 0;
+        const int r = big_eval(t, f, b);
+        if (r != kResNone) return r;
+    }
+    return big_eval(t, f, b);
+}
+
+__device__ __forceinline__ void big_canon(const BigTab &t, Fsm &f) {
+    if (t.st[kBigStateWords * f.cur + 5] & 1u) f.k = 0;
+}
+
 // First decimated index of input buffer `buf`: floor(buf * spb / D)
 // (decimated sample j comes from input D*(j+1)-1).
 __device__ __forceinline__ uint64_t buffer_start(uint64_t buf, uint32_t spb, uint32_t D) {
@@ -591,8 +706,10 @@ __device__ __forceinline__ bool seg_state_equal(const SegState &a, const SegStat
     return eq;
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32_t parity, uint32_t mode,
                                                        uint32_t slot) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t big_lds[];
     const uint32_t seg = blockIdx.x;
     const uint32_t nseg = p.num_captures * p.segs_per_cap;
     const uint32_t cap = seg / p.segs_per_cap;
@@ -626,7 +743,20 @@ __global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32
         atomicAdd(&p.changed[slot], 1u);            // a full round counts every segment
     }
 
-    const LaneTables t = load_tables(p.tables);
+    LaneTables t{};
+    BigTab bt{};
+    if constexpr (BIG) {
+        for (uint32_t i = lane; i < p.big_words; i += 64) big_lds[i] = p.big[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bt.st = big_lds + kBigHeaderWords;
+        bt.tr = bt.st + kBigStateWords * big_lds[0];
+        bt.max_bits = big_lds[1];
+        t.max_bits = bt.max_bits;
+    } else {
+        t = load_tables(p.tables);
+    }
     const uint64_t *bounds = p.seg_bounds + (size_t)cap * (p.segs_per_cap + 1);
     const uint64_t seg_start = rfl64(bounds[ls]);
     const uint64_t seg_end = rfl64(bounds[ls + 1]);
@@ -718,68 +848,84 @@ __global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32
             const uint32_t run_end = e1 < seg_n ? e1 : seg_n;
             const uint32_t n = run_end - pos;       // >= 1 samples with level b
             const uint32_t s = f.cur;
-            const uint32_t row = rl(t.srow, s), kto = rl(t.skto, s);
-            const uint32_t wait = trig_wait(t, row, kto, f.k, f.nbits);
+            uint32_t row = 0, kto = 0, wait = 0, wmin = kNone;
+            if constexpr (BIG) {
+                wmin = big_wait(bt, s, f.k, f.nbits);
+            } else {
+                row = rl(t.srow, s);
+                kto = rl(t.skto, s);
+                wait = trig_wait(t, row, kto, f.k, f.nbits);
+            }
             if (s != 0) {
                 // one evaluation per sample: any always/timeout/msg_complete
                 // trigger due inside the run?
-                if (__ballot(wait < n) == 0) {
+                if (BIG ? !(wmin < n) : __ballot(wait < n) == 0) {
                     f.k = sat_add(f.k, n);
                     if (e1 >= seg_n) {              // ran into the end of the segment
                         pos = seg_n;
                         ci = cia;
-                        canon(t, f);
+                        if constexpr (BIG) big_canon(bt, f);
+                        else canon(t, f);
                         continue;
                     }
                     // the edge sample itself: level flips, prev = b
                     const uint32_t b2 = b ^ 1u;
-                    const uint64_t ball = __ballot(trig_match(t, row, kto, f.k, b, b2, f.nbits));
+                    int fired;
+                    if constexpr (BIG) {
+                        fired = big_match(bt, s, f.k, b, b2, f.nbits);
+                    } else {
+                        const uint64_t ball = __ballot(trig_match(t, row, kto, f.k, b, b2, f.nbits));
+                        fired = ball ? (int)__builtin_ctzll(ball) : -1;
+                    }
                     pos = e1 + 1;
                     ci = cia + 1;
                     f.prev = b2;
-                    if (ball == 0) {                // edge ignored by this state
+                    if (fired < 0) {                // edge ignored by this state
                         f.k = sat_add(f.k, 1);
-                        canon(t, f);
+                        if constexpr (BIG) big_canon(bt, f);
+                        else canon(t, f);
                         continue;
                     }
-                    r = fsm_fire(t, f, s, (uint32_t)__builtin_ctzll(ball));
+                    r = BIG ? big_fire(bt, f, s, (uint32_t)fired) : fsm_fire(t, f, s, (uint32_t)fired);
                     at = e1;
                     dbg_fused++;
                 } else {
-                    const uint32_t w = wave_min(wait);      // < n
+                    const uint32_t w = BIG ? wmin : wave_min(wait);      // < n
                     f.k = sat_add(f.k, w);
                     pos += w;
                     ci = cia;
-                    r = fsm_step(t, f, b);          // fires
+                    r = BIG ? big_step(bt, f, b) : fsm_step(t, f, b);          // fires
                     at = pos;
                     pos += 1;
                 }
             } else {
                 // reset evaluates twice per sample (state_machine.c:526-538)
-                const uint32_t q = wave_min(wait);
+                const uint32_t q = BIG ? wmin : wave_min(wait);
                 uint32_t m = q == kNone ? n : (q >> 1);
                 if (m > n) m = n;
                 if (m > 0) {
                     f.k = sat_add(f.k, 2ull * m);
                     pos += m;
                     ci = cia;
-                    canon(t, f);
+                    if constexpr (BIG) big_canon(bt, f);
+                    else canon(t, f);
                     continue;
                 }
-                r = fsm_step(t, f, b);
+                r = BIG ? big_step(bt, f, b) : fsm_step(t, f, b);
                 at = pos;
                 pos += 1;
                 ci = cia;
             }
         } else {
             // ---- the state machine sees a level change at pos -----------------------
-            r = fsm_step(t, f, b);
+            r = BIG ? big_step(bt, f, b) : fsm_step(t, f, b);
             f.prev = b;                             // sm_process: prev_bit = data[i]
             at = pos;
             pos += 1;
             ci = cia;
         }
-        canon(t, f);
+        if constexpr (BIG) big_canon(bt, f);
+        else canon(t, f);
         if (r == kResOutput) {
             if (nmsg < p.msg_slots) {
                 if (lane == 0) {
@@ -968,7 +1114,14 @@ hipError_t launch_fsm_round(const FsmParams &p, uint32_t parity, uint32_t mode, 
                             hipStream_t stream) {
     const uint32_t nseg = p.num_captures * p.segs_per_cap;
     if (nseg == 0) return hipSuccess;
-    hipLaunchKernelGGL(fsm_round_kernel, dim3(nseg), dim3(64), 0, stream, p, parity, mode, slot);
+    if (p.big) {
+        const size_t lds = (size_t)p.big_words * sizeof(uint32_t);
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&fsm_round_kernel<true>), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fsm_round_kernel<true>, dim3(nseg), dim3(64), lds, stream, p, parity, mode, slot);
+    } else {
+        hipLaunchKernelGGL(fsm_round_kernel<false>, dim3(nseg), dim3(64), 0, stream, p, parity, mode, slot);
+    }
     return hipGetLastError();
 }
 

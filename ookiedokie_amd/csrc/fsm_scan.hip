@@ -36,6 +36,7 @@
 // anything.  Both paths give identical results (tests run both against the
 // oracle).
 #include "kernels.hpp"
+#include "common.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -3001,7 +3002,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     if (e != hipSuccess) return e;
     // with span tables and 64-leaf blocks the leaf kernel runs one wave per block (OOKD_SCAN_LEAF=block: the
     // workgroup-per-block form, which is also what runs without span tables)
-    const char *const leaf_env = getenv("OOKD_SCAN_LEAF");       // (looked up per launch: the tests switch it)
+    const char *const leaf_env = dev_getenv("OOKD_SCAN_LEAF");       // (looked up per launch: the tests switch it)
     const size_t lds_wave = wave_lds_bytes(a.D, a.S);
     const bool wave_form = a.lt_off && a.lt_words && a.lt_words <= kLtLdsWords && a.leaf_block == 64 && lds_wave <= 60u * 1024u &&
                            !(leaf_env && leaf_env[0] == 'b');
@@ -3054,7 +3055,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
             sim_lds = lds;
         }
     }
-    static const char *const grid_env = getenv("OOKD_SCAN_GRID");
+    static const char *const grid_env = dev_getenv("OOKD_SCAN_GRID");
     const uint32_t leaf_blocks = grid_env ? (uint32_t)atoi(grid_env) : leaf_grid;
     const uint32_t emit_blocks = grid_env ? (uint32_t)atoi(grid_env) : emit_grid;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);

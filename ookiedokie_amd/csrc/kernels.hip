@@ -14,6 +14,7 @@
 // rounded multiply and add, exactly as the reference's scalar build; fused
 // multiply-adds are written explicitly with __builtin_fmaf.
 #include "kernels.hpp"
+#include "common.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -1284,7 +1285,7 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
             fn = exact ? reinterpret_cast<const void *>(&fir1_bits_kernel<true, kFir1RLong>)
                        : reinterpret_cast<const void *>(&fir1_bits_kernel<false, kFir1RLong>);
         }
-        static const size_t lds_pad = getenv("OOKD_FIR1_LDS_PAD") ? (size_t)atoi(getenv("OOKD_FIR1_LDS_PAD")) : 0;   // experiment: caps the waves per CU
+        static const size_t lds_pad = dev_getenv("OOKD_FIR1_LDS_PAD") ? (size_t)atoi(dev_getenv("OOKD_FIR1_LDS_PAD")) : 0;   // experiment: caps the waves per CU
         const size_t lds_req = lds + lds_pad;
         hipError_t e = ensure_dynamic_lds(fn, lds_req);
         if (e != hipSuccess) return e;

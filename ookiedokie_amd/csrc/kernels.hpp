@@ -196,6 +196,14 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream);
 
 constexpr int kMaxStates = 64;
 constexpr int kMaxTriggers = 64;
+// Devices beyond that (the reference allocates states and triggers dynamically, state_machine.c:135-235)
+// run through the round form with the tables in LDS instead of in the lanes' registers:
+//   big[0..3] = states, max_bits, triggers, quiet state;
+//   per state   (6 words): kmin, kmax, kto (0xffffffff = none), first trigger, end trigger, flags
+//   per trigger (3 words): kmin, kmax, cond | action << 8 | next << 16
+constexpr int kMaxStatesBig = 1024;
+constexpr int kMaxTriggersBig = 2048;
+constexpr uint32_t kBigHeaderWords = 4, kBigStateWords = 6, kBigTrigWords = 3;
 
 struct FsmTablesDev {
     uint32_t num_states, max_bits, num_triggers;
@@ -262,6 +270,8 @@ struct FsmParams {
     uint32_t tiles_per_cap;
     uint32_t tile_shift;        // log2(outputs per tile)
     uint32_t stamp_bits;
+    const uint32_t *big;        // tables of a device with more than 64 states / triggers (see kMaxStatesBig), or null
+    uint32_t big_words;
 };
 
 // level of decimated sample `pos` of capture `cap` (pos may be -1 for a chunk: the sample in front of it)

@@ -32,7 +32,7 @@ namespace {
     } while (0)
 
 constexpr uint32_t kIterBatch = 4;      // FSM fix-point rounds queued per host sync
-constexpr uint32_t kMaxIter = 1u << 16;
+
 constexpr uint64_t kHostMsgFirst = 2048;    // messages copied with the header
 // control block of the streaming front end: ticket heads | per-chunk counters | chunk ends
 constexpr size_t kCtlHeads = 0, kCtlDone = (size_t)kStreamHeads * kStreamHeadStride, kCtlChunkEnd = kCtlDone + kMaxChunks,
@@ -213,6 +213,39 @@ uint32_t quiet_state(const ookd_device &d) {
     return 0;
 }
 
+// kernels.hpp: kMaxStatesBig -- the packed tables of a device with more than 64 states / triggers
+std::vector<uint32_t> big_tables(const ookd_device &d, uint32_t quiet) {
+    const uint64_t NONE = ~0ull;
+    auto c32 = [&](uint64_t v) { return v == NONE ? 0xffffffffu : (uint32_t)v; };       // finite bounds are < 2^31
+    const size_t ns = d.state_duration_us.size(), nt = d.trig_cond.size();
+    std::vector<uint32_t> w(kBigHeaderWords + kBigStateWords * ns + kBigTrigWords * nt);
+    w[0] = (uint32_t)ns;
+    w[1] = d.num_bits;
+    w[2] = (uint32_t)nt;
+    w[3] = quiet;
+    for (size_t s = 0; s < ns; ++s) {
+        uint32_t *r = &w[kBigHeaderWords + kBigStateWords * s];
+        r[0] = c32(d.state_kmin[s]);
+        r[1] = c32(d.state_kmax[s]);
+        r[2] = c32(d.state_kto[s]);
+        r[3] = d.trig_begin[s];
+        r[4] = d.trig_begin[s + 1];
+        bool irrelevant = d.state_kmin[s] == 0 && d.state_kmax[s] == NONE;
+        for (uint32_t i = d.trig_begin[s]; i < d.trig_begin[s + 1]; ++i) {
+            if (d.trig_kmin[i] != 0 || d.trig_kmax[i] != NONE) irrelevant = false;
+            if (d.trig_cond[i] == 4 && d.state_kto[s] != NONE) irrelevant = false;
+        }
+        r[5] = irrelevant ? 1u : 0u;
+    }
+    for (size_t i = 0; i < nt; ++i) {
+        uint32_t *r = &w[kBigHeaderWords + kBigStateWords * ns + kBigTrigWords * i];
+        r[0] = c32(d.trig_kmin[i]);
+        r[1] = c32(d.trig_kmax[i]);
+        r[2] = (uint32_t)d.trig_cond[i] | ((uint32_t)d.trig_action[i] << 8) | ((uint32_t)d.trig_next[i] << 16);
+    }
+    return w;
+}
+
 void fill_fsm_tables(const ookd_device &d, FsmTablesDev &t) {
     const uint64_t NONE = ~0ull;
     const size_t ns = d.state_duration_us.size();
@@ -228,6 +261,8 @@ void fill_fsm_tables(const ookd_device &d, FsmTablesDev &t) {
         t.state_kmax[s] = NONE;
         t.state_kto[s] = NONE;
     }
+    t.quiet_state = quiet_state(d);
+    if (ns > (size_t)kMaxStates || nt > (size_t)kMaxTriggers) return;    // a big device: only the counts (its tables: big_tables)
     for (size_t s = 0; s < ns; ++s) {
         t.state_kmin[s] = d.state_kmin[s];
         t.state_kmax[s] = d.state_kmax[s];
@@ -303,6 +338,7 @@ struct ookd_rx {
     bool pipe_ok = false;
     uint64_t pipe_chunk_in = 0;     // target input samples per chunk
     hipStream_t s_front = nullptr, s_chain = nullptr;
+    std::vector<hipStream_t> dummy_streams;     // OOKD_PIPE_DUMMY experiment
     hipEvent_t ev_start = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_c0, ev_c1;       // per chunk: front-end kernel start / stop
     std::vector<Chunk> chunks;      // of the last run (empty: not pipelined)
@@ -328,6 +364,8 @@ struct ookd_rx {
     bool have_fsm = false;
     uint32_t num_bits = 0;
     DevBuf<FsmTablesDev> d_tables;
+    DevBuf<uint32_t> d_big;         // packed tables of a device with more than 64 states / triggers (kernels.hpp)
+    bool big_device = false;
 
     // capacity
     uint64_t max_samples = 0;
@@ -406,6 +444,7 @@ struct ookd_rx {
         d_taps.release();
         d_mfma_a.release();
         d_tables.release();
+        d_big.release();
         d_bits.release();
         d_fir.release();
         d_halo.release();
@@ -424,6 +463,7 @@ struct ookd_rx {
         for (auto &e : ev_c1) if (e) (void)hipEventDestroy(e);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_end) (void)hipEventDestroy(ev_end);
+        for (hipStream_t d : dummy_streams) if (d) (void)hipStreamDestroy(d);
         if (s_front) (void)hipStreamDestroy(s_front);
         if (s_chain) (void)hipStreamDestroy(s_chain);
         d_blk_count.release();
@@ -503,7 +543,7 @@ struct ookd_rx {
         p.p_hi_w = p_hi_w;
         p.mfma_g = mfma_g;
         {
-            static const uint32_t dbg = getenv("OOKD_MFMA_DEBUG") ? (uint32_t)atoi(getenv("OOKD_MFMA_DEBUG")) : 0u;
+            static const uint32_t dbg = dev_getenv("OOKD_MFMA_DEBUG") ? (uint32_t)atoi(dev_getenv("OOKD_MFMA_DEBUG")) : 0u;
             p.mfma_debug = dbg;
         }
         p.recompute_count = &d_hdr.p->recompute;
@@ -544,6 +584,8 @@ struct ookd_rx {
     FsmParams fsm_params() const {
         FsmParams f{};
         f.tables = d_tables.p;
+        f.big = big_device ? d_big.p : nullptr;
+        f.big_words = big_device ? (uint32_t)d_big.n : 0u;
         f.bits = d_bits.p;
         f.words_per_cap = run_words;
         f.edges = d_edges.p;
@@ -854,7 +896,7 @@ int ookd_rx::front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d
         ctl.num_chunks = 0;
         ctl.num_caps = run_caps;
         ctl.waves_per_cu = stream_waves;
-        ctl.static_stride = getenv("OOKD_STREAM_STRIDE") ? 1u : 0u;
+        ctl.static_stride = dev_getenv("OOKD_STREAM_STRIDE") ? 1u : 0u;
         front_launches = 1;
         HIPCHK(launch_front_stream(fp, ctl, exact, false, stream, ev[0], ev[1]));
     } else {
@@ -943,7 +985,9 @@ int ookd_rx::fsm_to_fixpoint(const FsmStateDev *first, bool fresh, bool force_fi
         if (conv) break;
         // every round settles at least one more segment's incoming state, left to right: a capture of
         // S segments is through after at most S + 1 rounds -- more would be a bug, not a hard input
-        if (rounds > std::max<uint32_t>(kMaxIter, fp.num_captures * fp.segs_per_cap + 2 * kIterBatch)) {
+        // (captures are independent chains of segs_per_cap segments: the bound is per capture, and it IS the
+        //  check -- a fix-point that has not closed by then is a bug, not a hard input)
+        if (rounds > fp.segs_per_cap + 2 * kIterBatch) {
             set_error("state machine fix-point did not converge in %u rounds", rounds);
             return OOKD_ERR_ARG;
         }
@@ -1425,7 +1469,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         MfmaTaps mt;
         bool use_mfma = false;
         if (rx->num_stages == 1 && rx->stage[0].decim == 1 && !(cfg->flags & OOKD_RX_FIR_VALU) &&
-            !getenv("OOKD_FRONT_STREAM") && !getenv("OOKD_FIR_VALU") &&
+            !dev_getenv("OOKD_FRONT_STREAM") && !dev_getenv("OOKD_FIR_VALU") &&
             mfma_prepare_taps(filter->stages[0].taps.data(), rx->stage[0].ntaps, mt)) {
             float lo_n, hi_n, lo_w, hi_w;
             band_from_error(mfma_error_bound(mt, rx->stage[0].ntaps, false), rx->p_star, lo_n, hi_n);
@@ -1448,7 +1492,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             // wave tiles per wave of a workgroup: more for the long filters, whose workgroups fill a CU and
             // fetch a 20 / 36 KB image each (config2 sweep: 474 / 545 / 599 / 623 / 635 Gsamples/s at 2 / 4 / 8 / 16 / 32)
             rx->mfma_g = mt.ksteps <= 6 ? 4u : mt.ksteps <= 10 ? 16u : 32u;
-            if (const char *g = getenv("OOKD_MFMA_G")) rx->mfma_g = (uint32_t)std::min(4096, std::max(1, atoi(g)));
+            if (const char *g = dev_getenv("OOKD_MFMA_G")) rx->mfma_g = (uint32_t)std::min(4096, std::max(1, atoi(g)));
         }
     }
     if (filter && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) && !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
@@ -1472,9 +1516,10 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     if (device) {
         const size_t ns = device->state_duration_us.size();
         const size_t nt = device->trig_cond.size();
-        if (ns > (size_t)kMaxStates || nt > (size_t)kMaxTriggers) {
-            set_error("device has %zu states / %zu triggers, this build supports %d / %d", ns, nt,
-                      kMaxStates, kMaxTriggers);
+        const bool big = ns > (size_t)kMaxStates || nt > (size_t)kMaxTriggers;
+        if (ns > (size_t)kMaxStatesBig || nt > (size_t)kMaxTriggersBig || device->num_bits > 254) {
+            set_error("device has %zu states / %zu triggers / %u bits, this build supports %d / %d / 254", ns, nt,
+                      device->num_bits, kMaxStatesBig, kMaxTriggersBig);
             return nullptr;
         }
         // the kernel counts elapsed samples in 32 bits (saturating)
@@ -1496,6 +1541,17 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         if (hipMemcpy(rx->d_tables.p, t.get(), sizeof(FsmTablesDev), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("table upload failed");
             return nullptr;
+        }
+        if (big) {
+            // more than 64 states / triggers: the round form with the tables in LDS (the scan's tables and the
+            // lane-resident ones stop at 64)
+            const std::vector<uint32_t> w = big_tables(*device, t->quiet_state);
+            if (rx->d_big.alloc(w.size()) != OOKD_OK) return nullptr;
+            if (hipMemcpy(rx->d_big.p, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("table upload failed");
+                return nullptr;
+            }
+            rx->big_device = true;
         }
         rx->have_fsm = true;
         rx->num_bits = device->num_bits;
@@ -1536,9 +1592,9 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     rc |= rx->d_ctl.alloc(kCtlWords);
     // the streaming (persistent) form is experimental: it caps the front end's residency, but is
     // slower than the hardware-dispatched grid; OOKD_FRONT_STREAM=1 selects it
-    rx->front_grid = (cfg->flags & OOKD_RX_FRONT_GRID) != 0 || !getenv("OOKD_FRONT_STREAM");
-    if (const char *w = getenv("OOKD_STREAM_WAVES")) rx->stream_waves = (uint32_t)std::max(1, atoi(w));
-    if (const char *w = getenv("OOKD_FRONT_LAUNCH_LOG2")) rx->front_launch_outputs = 1ull << std::min(40, std::max(16, atoi(w)));
+    rx->front_grid = (cfg->flags & OOKD_RX_FRONT_GRID) != 0 || !dev_getenv("OOKD_FRONT_STREAM");
+    if (const char *w = dev_getenv("OOKD_STREAM_WAVES")) rx->stream_waves = (uint32_t)std::max(1, atoi(w));
+    if (const char *w = dev_getenv("OOKD_FRONT_LAUNCH_LOG2")) rx->front_launch_outputs = 1ull << std::min(40, std::max(16, atoi(w)));
     rc |= rx->d_blk_offset.alloc(caps * blocks + 1 + kMaxChunks);     // (a pipelined run keeps one total per chunk)
     rc |= rx->d_group_total.alloc((caps * blocks + kScanGroup - 1) / kScanGroup + 1);
     rc |= rx->d_edges.alloc(rx->edge_capacity + 64);
@@ -1560,7 +1616,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rx->scan_S = (uint32_t)device->state_duration_us.size();
         rx->scan_max_bits = device->num_bits;
         rx->scan_D = rx->scan_S * (device->num_bits + 2) + 3;
-        rx->scan_ok = !(cfg->flags & OOKD_RX_FSM_ROUNDS) && rx->scan_D <= 384 && device->num_bits <= 254;
+        rx->scan_ok = !(cfg->flags & OOKD_RX_FSM_ROUNDS) && rx->scan_D <= 384 && device->num_bits <= 254 && !rx->big_device;
         std::vector<uint16_t> stuck_src;        // normal codes an inert edge can leave stuck (domain extension)
         std::vector<uint8_t> stuck_rows;
         if (rx->scan_ok && !(cfg->flags & OOKD_RX_SCAN_SIMS)) {
@@ -1674,7 +1730,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         // words and tile infos start out zero and every run zeroes what the run before wrote
         FrontParams probe = rx->front_params(nullptr, 0);
         probe.n_out = rx->max_n_out;
-        rx->sparse = front_sparse_capable(probe) && !getenv("OOKD_DENSE_BITS");
+        rx->sparse = front_sparse_capable(probe) && !dev_getenv("OOKD_DENSE_BITS");
         if (rx->sparse &&
             (hipMemset(rx->d_bits.p, 0, rx->d_bits.n * sizeof(uint64_t)) != hipSuccess ||
              hipMemset(rx->d_tile_info.p, 0, rx->d_tile_info.n * sizeof(uint32_t)) != hipSuccess)) {
@@ -1702,10 +1758,10 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         // hardware-dispatched front end the chain's kernels are hardly dispatched while a front-end grid
         // has workgroups pending, and the chunked run is slower than the whole one
         uint64_t want = cfg->pipeline_chunk_samples;
-        if (!want && getenv("OOKD_PIPELINE")) want = kPipeDefaultChunk;
+        if (!want && dev_getenv("OOKD_PIPELINE")) want = kPipeDefaultChunk;
         rx->pipe_chunk_in = want ? want : kPipeDefaultChunk;
         rx->pipe_ok = want != 0 && rx->have_fsm && rx->scan_ok && tuned && !(cfg->flags & OOKD_RX_NO_PIPELINE) &&
-                      cfg->pipeline_chunk_samples != ~0ull && !getenv("OOKD_NO_PIPELINE") &&
+                      cfg->pipeline_chunk_samples != ~0ull && !dev_getenv("OOKD_NO_PIPELINE") &&
                       rx->max_n_out >= 2 * (rx->pipe_chunk_in / rx->total_decim);
     }
     if (rx->pipe_ok) {
@@ -1713,7 +1769,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         // slows the front end: the dispatcher deals workgroups evenly over the XCDs).
         // OOKD_PIPE_MASKS=front,chain (hex, per 32 CUs; 0 = no mask) overrides.
         uint32_t mf = 0x55555555u, mc = 0xAAAAAAAAu;
-        if (const char *m = getenv("OOKD_PIPE_MASKS")) {
+        if (const char *m = dev_getenv("OOKD_PIPE_MASKS")) {
             char *end = nullptr;
             mf = (uint32_t)strtoul(m, &end, 16);
             mc = (end && *end == ',') ? (uint32_t)strtoul(end + 1, nullptr, 16) : 0u;
@@ -1730,13 +1786,14 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             return e;
         };
         bool made = make(rx->s_front, mf) == hipSuccess;
-        if (const char *k = getenv("OOKD_PIPE_DUMMY")) {       // experiment: shift the queue -> pipe assignment
+        if (const char *k = dev_getenv("OOKD_PIPE_DUMMY")) {       // experiment: shift the queue -> pipe assignment
             for (int i = 0; i < atoi(k); ++i) {
                 hipStream_t d = nullptr;
                 (void)hipStreamCreateWithFlags(&d, hipStreamNonBlocking);
                 // a queue only exists once something was submitted to it
                 (void)hipMemsetAsync(rx->d_hdr.p, 0, 4, d);
                 (void)hipStreamSynchronize(d);
+                rx->dummy_streams.push_back(d);         // destroyed with the context
             }
         }
         if (!made || make(rx->s_chain, mc) != hipSuccess ||
@@ -1751,7 +1808,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
     }
     rx->gate = static_cast<ookd_rx_gate *>(cfg->front_gate);
     // (tests: start the tile stamp near its wrap-around)
-    if (const char *e = getenv("OOKD_TILE_STAMP_START")) rx->tile_stamp = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 0), kTileStampMax);
+    if (const char *e = dev_getenv("OOKD_TILE_STAMP_START")) rx->tile_stamp = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 0), kTileStampMax);
     return rx.release();
 }
 

@@ -644,6 +644,39 @@ def test_random_devices_match_oracle(ok, oracle):
             rx.close()
 
 
+def test_devices_beyond_64_states_run_through_the_round_form(ok, oracle):
+    """The reference allocates states and triggers dynamically (state_machine.c:135-235).  Devices with more
+    than 64 of either decode through the round form with their tables in LDS: a 100-state / ~250-trigger
+    random machine and one state with 70 triggers (more than one lane group), over a thousand segments."""
+    from tests.test_oracle import _random_fsm
+    rng = np.random.default_rng(4242)
+    for it, (ns, mt) in enumerate(((100, 4), (100, 5), (3, 72), (130, 3))):
+        rate = int(rng.choice([3000000, 1000000]))
+        od = _random_fsm(oracle, rng, rate, ns=ns, max_triggers=mt)
+        assert len(od.state_duration_us) > 64 or len(od.trig_cond) > 64
+        d = ok.Device.from_tables(
+            max_bits=od.max_bits, sample_rate=rate, state_duration_us=od.state_duration_us,
+            state_timeout_us=od.state_timeout_us, trig_begin=od.trig_begin, trig_cond=od.trig_cond,
+            trig_action=od.trig_action, trig_next=od.trig_next, trig_duration_us=od.trig_duration_us)
+        scale = rate / 1e6
+        runs = [max(1, int(rng.choice([30, 60, 100, 200, 250, 400, 1000, 5000]) * scale
+                       * rng.uniform(0.8, 1.2))) for _ in range(6000)]
+        stream = stream_from_runs(runs)
+        iq = _iq_from_stream(stream)
+        n = iq.size // 2
+        spb = 1024
+        segb = max(1, n // spb // 1100)         # > 1 000 segments
+        rx = ok.Receiver(None, d, max_samples=n, samples_per_buffer=spb, segment_buffers=segb,
+                         message_slots=2 * spb * segb + 2, message_capacity=1 << 22, edge_capacity=n)
+        got = rx.rx(iq)
+        want = oracle.rx(iq, None, 0.1, od, spb, msg_cap=1 << 22)
+        assert got.stats["fsm_path"] == 2 and got.stats["num_segments"] >= 1000, got.stats
+        assert list(got.msg_samples) == list(want.msg_samples), it
+        assert (got.payloads == want.payloads).all(), it
+        assert got.stats["num_errors"] == len(want.err_samples), it
+        rx.close()
+
+
 # ------------------------------------------------------- batched / sharded ----
 
 def test_batched_captures_are_independent(ok, oracle, vectors):
@@ -1071,8 +1104,10 @@ def test_sparse_bit_words_do_not_leak_between_runs(ok, oracle, vectors, chunk, s
     every run (which cleans up) and never (stale tiles of many runs pile up), and across the wrap of the
     20-bit stamp: bits, edges and messages of every run must be the oracle's."""
     if stream_form:
+        monkeypatch.setenv("OOKD_DEVELOPER", "1")
         monkeypatch.setenv("OOKD_FRONT_STREAM", "1")
     if stamp0 is not None:
+        monkeypatch.setenv("OOKD_DEVELOPER", "1")
         monkeypatch.setenv("OOKD_TILE_STAMP_START", str(stamp0))
     g, a = _g1(vectors, noise_seed=41)
     rng = np.random.default_rng(42)
@@ -1137,6 +1172,7 @@ def test_fresh_contexts_and_shards_repeat_exactly(ok, oracle, vectors, filt, lea
     tables), otherwise the wave-per-block one."""
     from ookiedokie_amd.distributed import shard_bounds
     if leaf_form:
+        monkeypatch.setenv("OOKD_DEVELOPER", "1")
         monkeypatch.setenv("OOKD_SCAN_LEAF", leaf_form)
     g, iq = _g1(vectors, noise_seed=21)
     n = iq.size // 2

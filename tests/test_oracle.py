@@ -275,17 +275,17 @@ def test_random_streams_match_reference_fsm_fixtures(oracle, vectors):
             assert list(es) == want["err_samples"]
 
 
-def _random_fsm(O, rng, rate):
+def _random_fsm(O, rng, rate, ns=None, max_triggers=4):
     """A random (mostly nonsensical) device: exercises every trigger kind,
     reset without 'always', states with zero-duration windows, etc."""
     import numpy as np
-    ns = int(rng.integers(2, 6))
+    ns = int(rng.integers(2, 6)) if ns is None else ns
     durs = [0, 0, 30, 100, 250]
     sdur = rng.choice(durs, ns)
     sto = rng.choice([0, 0, 50, 400, 1000], ns)
     tbeg, cond, act, nxt, tdur = [0], [], [], [], []
     for s in range(ns):
-        nt = int(rng.integers(1, 4))
+        nt = int(rng.integers(1, max_triggers))
         for _ in range(nt):
             if s == 0 and rng.random() < 0.6:
                 c = 1

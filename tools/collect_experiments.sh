@@ -12,7 +12,7 @@ timeout -k 5 200 ./tools/stream_bw 8 > $OUT/stream_bw.txt 2>&1 &&
 timeout -k 5 200 ./tools/stream_bw2 4 > $OUT/stream_bw2.txt 2>&1 &&
 timeout -k 5 300 python tools/cu_mask_probe.py 28 > $OUT/cu_mask_probe.txt 2>&1 &&
 ( echo "# hardware-dispatched grid form"; timeout -k 5 200 python tools/front_diag.py 28 | grep grid;
-  for W in 12 16; do echo "# streaming (persistent) form, $W waves per CU"; OOKD_FRONT_STREAM=1 OOKD_STREAM_WAVES=$W timeout -k 5 200 python tools/front_diag.py 28 | grep stream; done ) > $OUT/front_forms.txt 2>&1 &&
+  for W in 12 16; do echo "# streaming (persistent) form, $W waves per CU"; OOKD_DEVELOPER=1 OOKD_FRONT_STREAM=1 OOKD_STREAM_WAVES=$W timeout -k 5 200 python tools/front_diag.py 28 | grep stream; done ) > $OUT/front_forms.txt 2>&1 &&
 for V in "whole OOKD_NO_PIPELINE=1" "pipelined_1GiB_chunks OOKD_PIPELINE=1"; do set -- $V; env $2 timeout -k 10 300 python bench.py --contexts 1 --steps 8 --warmup 2 --no-cpu-baseline --no-sub-records > $OUT/bench_$1.json 2> $OUT/bench_$1.err; done
 cd /tmp && export TMPDIR=/tmp
 OOKD_PIPELINE=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/pipe_trace -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-sub-records > $OUT/pipe_trace.log 2>&1
