@@ -1550,7 +1550,8 @@ __device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, 
     }
 }
 
-__global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
+constexpr int kWaveK = 4;               // chains per lane in flight (8: 192 registers, two waves per SIMD)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void scan_leaf_wave_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ LTab T;
     __shared__ uint64_t s_resume[64];
@@ -1727,15 +1728,9 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
             uint32_t base = 0;
             while (base < nitem) {
                 const uint32_t left = (nitem - base + 63u) / 64u;
-                if (left >= 8) {
-                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
-                    base += 8 * 64;
-                } else if (left > 5) {
-                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
-                    base = nitem;
-                } else if (left > 3) {
-                    wave_compose<5>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
-                    base = nitem;
+                if (left >= kWaveK) {
+                    wave_compose<kWaveK>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base += kWaveK * 64;
                 } else if (left > 1) {
                     wave_compose<3>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
                     base = nitem;
