@@ -2,7 +2,7 @@
 # per-kernel stats (rocprofv3 --kernel-trace --stats) of a bench command:  tools/kstats.sh <tag> [bench args]
 set -o pipefail
 TAG=$1; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r03}/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sub-records "$@" > $OUT/stats.log 2>&1

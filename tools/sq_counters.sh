@@ -3,7 +3,7 @@
 # Two PMC passes (8 SQ slots each), kernel trace only beside them.
 set -o pipefail
 TAG=${1:-sq}; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r03}/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/p1 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --contexts 1 --no-sub-records "$@" > $OUT/p1.log 2>&1 &&

@@ -2,7 +2,7 @@
 # SQ counters of the front-end kernels for an arbitrary python command:  tools/sq_counters_cmd.sh <tag> <script> [args...]
 set -o pipefail
 TAG=$1; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r03/$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${ROUND:-r03}/$TAG
 mkdir -p $OUT
 SCRIPT=$GRAFT_REPO_ROOT/$1; shift
 cd /tmp && export TMPDIR=/tmp

@@ -18,7 +18,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "fir1_bits_kernel"
+KERNEL = "fir1_mfma_kernel"
 SAMPLES_PER_LAUNCH = 1 << 29          # the front end of a 2^32-sample capture goes out as 8 grid launches
 ALGO_BYTES = 4.125 * SAMPLES_PER_LAUNCH
 
@@ -48,7 +48,7 @@ def main():
         hbm = (2.0 * fetch + write) * 1024.0
         with open(os.path.join(dst, "traffic.json"), "w") as f:
             json.dump({
-                "kernel": "ookd::" + KERNEL + "<false>",
+                "kernel": "ookd::" + KERNEL + "<4>",
                 "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python "
                            "bench.py --steps 4 --warmup 1 --contexts 1 --no-cpu-baseline --no-sub-records (two separate passes, "
                            "tools/collect_profiles.sh)",
@@ -62,6 +62,18 @@ def main():
     stats1 = sorted(glob.glob(os.path.join(src, "stats1", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if stats1:
         shutil.copy(stats1[-1], os.path.join(dst, rnd + "_kernel_stats_one_context.csv"))
+    # SQ counters of the front-end kernel with every window loud (tools/sq_counters.sh worst --no-quiet-skip) and of configs[2]
+    for tag, out in (("worst", rnd + "_fir1_sq_counters.txt"), ("config2", rnd + "_fir1_sq_counters_255taps.txt")):
+        parts = []
+        for pp in ("p1", "p2"):
+            fsum = os.path.join(ROOT, "gpurun_out", rnd, tag, pp + "_summary.txt")
+            if os.path.exists(fsum):
+                parts.append(open(fsum).read())
+        if parts:
+            with open(os.path.join(dst, out), "w") as f:
+                f.write("# rocprofv3 --pmc <8 SQ counters> --kernel-trace, two passes (tools/sq_counters.sh / sq_counters_cmd.sh); per dispatch of the\n"
+                        "# front-end kernel (2^29 samples = 524 288 wave tiles of 1024 outputs); WAVE / WAIT / ACTIVE in quad-cycles\n")
+                f.write("".join(parts))
     for name in ("bench_line", "bench_line_dec4", "bench_line_batch", "bench_line_1GiB"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p):
