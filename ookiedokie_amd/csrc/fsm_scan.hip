@@ -1550,8 +1550,9 @@ __device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, 
     }
 }
 
-constexpr int kWaveK = 4;               // chains per lane in flight (8: 192 registers, two waves per SIMD)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void scan_leaf_wave_kernel(ScanParams sp) {
+// (four chains per lane and three waves per SIMD instead of eight and two: 150 -> 142 us at 16 GiB, but 39 -> 44 us
+//  on a 1 GiB capture, where a block's own latency is all there is: not kept)
+__global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ LTab T;
     __shared__ uint64_t s_resume[64];
@@ -1728,9 +1729,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             uint32_t base = 0;
             while (base < nitem) {
                 const uint32_t left = (nitem - base + 63u) / 64u;
-                if (left >= kWaveK) {
-                    wave_compose<kWaveK>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
-                    base += kWaveK * 64;
+                if (left >= 8) {
+                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base += 8 * 64;
+                } else if (left > 5) {
+                    wave_compose<8>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
+                } else if (left > 3) {
+                    wave_compose<5>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
+                    base = nitem;
                 } else if (left > 1) {
                     wave_compose<3>(T, sc, edges, first, b, s_resume, D, count, lv, NR, rcpNB1, base);
                     base = nitem;
@@ -1923,6 +1930,7 @@ __device__ __noinline__ uint32_t leaf_step_fly_g(const LTab &T, const StuckCtx &
 //            from rows and chunk tables the leaf kernel stored for it -- 123 MB of stores per 16 GiB
 //            capture, and stores beside another context's front end cost it several times their share
 //            of the bandwidth: profiles/r02_interfere.txt.)
+constexpr uint32_t kEntryP0Blocks = 64;
 __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ LTab T;
@@ -1932,9 +1940,21 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     __syncthreads();
     if (*sp.fallback) return;
     const uint32_t LB = sp.leaf_block;
-    if (sp.entry_phase == 0) {
+    // Phases 0 and 2 do not depend on each other: one launch, the first kEntryP0Blocks workgroups take phase 0,
+    // the others phase 2 (one launch boundary and one table staging less on the chain's critical path).
+    uint32_t phase = sp.entry_phase, bid = blockIdx.x, nblk = gridDim.x;
+    if (phase == 0 && gridDim.x > kEntryP0Blocks) {
+        if (bid >= kEntryP0Blocks) {
+            phase = 2;
+            bid -= kEntryP0Blocks;
+            nblk -= kEntryP0Blocks;
+        } else {
+            nblk = kEntryP0Blocks;
+        }
+    }
+    if (phase == 0) {
         const uint32_t ngroups = sp.cap_group_off[sp.f.num_captures];
-        for (uint32_t gg = blockIdx.x * blockDim.x + threadIdx.x; gg < ngroups; gg += gridDim.x * blockDim.x) {
+        for (uint32_t gg = bid * blockDim.x + threadIdx.x; gg < ngroups; gg += nblk * blockDim.x) {
             uint32_t cap, lg;
             locate_group(sp, gg, cap, lg);
             const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
@@ -1965,11 +1985,11 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     const uint32_t SNB = T.S * T.NB1;
     const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + T.NB1 - 1) / T.NB1);
-    if (sp.entry_phase == 2) {
+    if (phase == 2) {
         // one lane per LEAF: which interval of its level's merged breakpoints the leaf's length falls into -- the
         // only search a leaf needs, done for all of them at once instead of inside the sequential walk of phase 1
         if (!fast) return;
-        for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)total * LB; t += (uint64_t)gridDim.x * blockDim.x) {
+        for (uint64_t t = (uint64_t)bid * blockDim.x + threadIdx.x; t < (uint64_t)total * LB; t += (uint64_t)nblk * blockDim.x) {
             const uint32_t gb = (uint32_t)(t / LB), l = (uint32_t)(t - (uint64_t)gb * LB);
             uint32_t cap, lb;
             locate_block(sp, gb, cap, lb);
@@ -3069,11 +3089,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.blk_in = a.blk_in;
     sp.rowz = a.rowz;
     sp.entry_phase = 0;
-    hipLaunchKernelGGL(scan_entry_kernel, dim3(64), dim3(256), 0, stream, sp);
-    if (a.lt_off && a.lt_merged && a.rowz) {
-        sp.entry_phase = 2;
-        hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
-    }
+    const bool with_phase2 = a.lt_off && a.lt_merged && a.rowz;
+    hipLaunchKernelGGL(scan_entry_kernel, dim3(kEntryP0Blocks + (with_phase2 ? 512u : 0u)), dim3(256), 0, stream, sp);
     sp.entry_phase = 1;
     hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(emit_blocks), dim3(kSimThreads), 0, stream, sp);
