@@ -46,6 +46,7 @@
 // loads, the quiet shortcut on the raw samples, sparse output with run stamps, tile
 // infos for the edge stage, no workgroup barrier (one wave = one workgroup).
 #include "kernels.hpp"
+#include "common.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -550,6 +551,337 @@ void fir1_mfma_kernel(const FrontParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// two decimate-by-2 stages (the backend default fs128_fs16_dec4: 16 taps / 2, 32 taps / 2) on the matrix cores
+// ---------------------------------------------------------------------------
+//
+// y2[m] = sum_k2 h2[k2] y1[2m + 1 - k2],  y1[j] = sum_k1 h1[k1] x[2j + 1 - k1]   (fir.c:290: the countdown starts at D)
+//       = sum_t g[t] x[4m + 3 - t],  g[t] = sum_{2 k2 + k1 = t} h2[k2] h1[k1],  t = 0 .. 2 (T2 - 1) + T1 - 1 <= 77:
+// ONE decimate-by-4 filter of up to 78 taps.  In real arithmetic the two are the same; the reference rounds every
+// multiply and add of both stages to fp32, and what that (and the fp32 accumulation here, and the part of g the two
+// fp16 pieces do not carry) can amount to goes into the guard band: an output inside it is recomputed exactly as the
+// reference does -- both stages, tap 0 first, separately rounded multiply and add -- from the capture itself.
+//
+// Product: a wave tile is 256 final outputs = 1024 input samples = 16 columns of 16 outputs (64 inputs each),
+// v_mfma_f32_16x16x32_f16.  With window sample j <-> input a0 + j, a0 = 4 M0 - 96:
+//   y2[M0 + 16 n + i] = sum_kk A[i][kk] win[64 n + kk],  A[i][kk] = g[4 i + 99 - kk],  kk = 0 .. 159: 5 K-steps of 32,
+// x 2 tap pieces x {re, im} = 20 MFMAs of 16 cycles per 1024 input samples (x 2 for a tile with samples beyond +-2048).
+// C: lane (n = l & 15, q = l >> 4), register r = output 16 n + 4 q + r.
+constexpr uint32_t kF2Out = 256;                // final outputs per wave tile
+constexpr uint32_t kF2Tp = 96;                  // input history in the window (>= 77)
+constexpr uint32_t kF2W = 4 * kF2Out + kF2Tp;   // 1120 window samples
+constexpr uint32_t kF2Nvec = kF2W / 4;          // 280 raw vectors
+constexpr int kF2Rounds = (int)((kF2Nvec + 63) / 64);
+constexpr int kF2KS = 5;
+constexpr int kF2Waves = 4;
+// one pad chunk (8 halfs) per 64 samples: column stride 72 halfs
+__host__ __device__ constexpr uint32_t f2slot(uint32_t j) { return j + 8u * (j >> 6); }
+constexpr uint32_t kF2Plane = f2slot(kF2W) + 8u;
+constexpr uint32_t kF2WaveBytes = kF2Plane * 2u * 2u;
+constexpr uint32_t kF2ImgBytes = kF2KS * 2u * 1024u;
+constexpr uint32_t kF2LdsBytes = kF2ImgBytes + kMfmaCtlBytes + kF2Waves * kF2WaveBytes;
+
+typedef float f4x __attribute__((ext_vector_type(4)));
+
+struct F2Taps {                 // what the exact recompute needs
+    gptrf taps1, taps2;
+    uint32_t n1, n2;
+};
+
+// Reference-order recomputation of final output m: the n2 stage-1 outputs it reads, each from the capture, then stage 2
+__device__ __forceinline__ float2 fir2_mfma_exact_output(const RawSrc &rs, const F2Taps &ft, int64_t m) {
+    const float s = 1.0f / 2048.0f;
+    float re2 = 0.0f, im2 = 0.0f;
+    for (uint32_t k2 = 0; k2 < ft.n2; ++k2) {
+        const int64_t j1 = 2 * m + 1 - (int64_t)k2;             // stage-1 output index
+        float re1 = 0.0f, im1 = 0.0f;
+        // (a stage-1 output in front of the capture comes out of the samples in front of it: zeros -- the reference's
+        //  stage buffers start as zeros, fir.c:282-293 -- or the previous shard's samples, the halo)
+        for (uint32_t k1 = 0; k1 < ft.n1; ++k1) {
+            const uint32_t w = fetch_raw_m(rs, 2 * j1 + 1 - (int64_t)k1);
+            const float xr = (float)(int16_t)(w & 0xffffu) * s;
+            const float xi = (float)(int16_t)(w >> 16) * s;
+            const float t = ft.taps1[k1];
+            const float pr = t * xr;
+            const float pi = t * xi;
+            re1 = re1 + pr;
+            im1 = im1 + pi;
+        }
+        const float t2 = ft.taps2[k2];
+        const float pr = t2 * re1;
+        const float pi = t2 * im1;
+        re2 = re2 + pr;
+        im2 = im2 + pi;
+    }
+    return make_float2(re2, im2);
+}
+
+__device__ __forceinline__ bool f2_interior(const MfmaTileCtx &c, uint64_t tile) {
+    const uint64_t i0 = tile * (4ull * kF2Out);
+    return c.aligned16 && i0 >= kF2Tp && i0 + 4ull * kF2Out <= c.rs.n_valid;
+}
+
+__device__ __forceinline__ void f2_issue_loads(const MfmaTileCtx &c, uint64_t tile, uint32_t tid, uint4 (&q)[kF2Rounds]) {
+    const gbytes src4 = uniform_ptr((gbytes)(c.rs.src + (tile * (4ull * kF2Out) - kF2Tp)));
+#pragma unroll
+    for (int i = 0; i < kF2Rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        q[i] = ld_nt4_at(src4, 16u * ((64u * (i + 1) <= kF2Nvec || v < kF2Nvec) ? v : kF2Nvec - 1u));
+    }
+}
+
+__device__ __noinline__ void f2_boundary_stage(RawSrc rs, uint64_t i0, uint32_t tid, uint4 *stage) {
+    for (uint32_t v = tid; v < kF2Nvec; v += 64u) {
+        const int64_t s0 = (int64_t)i0 - (int64_t)kF2Tp + 4 * (int64_t)v;
+        uint4 w;
+        w.x = fetch_raw_m(rs, s0);
+        w.y = fetch_raw_m(rs, s0 + 1);
+        w.z = fetch_raw_m(rs, s0 + 2);
+        w.w = fetch_raw_m(rs, s0 + 3);
+        stage[v] = w;
+    }
+}
+
+__device__ __forceinline__ void f2_boundary_loads(const MfmaTileCtx &c, uint64_t tile, uint32_t tid, unsigned char *win,
+                                                  uint4 (&q)[kF2Rounds]) {
+    uint4 *stage = reinterpret_cast<uint4 *>(win);
+    f2_boundary_stage(c.rs, tile * (4ull * kF2Out), tid, stage);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < kF2Rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        q[i] = stage[(64u * (i + 1) <= kF2Nvec || v < kF2Nvec) ? v : kF2Nvec - 1u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void f2_convert(const uint4 (&q)[kF2Rounds], uint32_t mask, uint32_t tid, _Float16 *pl_re,
+                                           _Float16 *pl_im) {
+#pragma unroll
+    for (int i = 0; i < kF2Rounds; ++i) {
+        const uint32_t v = tid + 64u * i;
+        if (64u * (i + 1) <= kF2Nvec || v < kF2Nvec) {
+            uint2 r4, i4;
+            cvt4(q[i], mask, r4, i4);
+            *reinterpret_cast<uint2 *>(pl_re + f2slot(4u * v)) = r4;
+            *reinterpret_cast<uint2 *>(pl_im + f2slot(4u * v)) = i4;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void f2_ksteps(const h8 *a_img, const _Float16 *pl_re, const _Float16 *pl_im, uint32_t tid,
+                                          f4x &are, f4x &aim) {
+    const uint32_t n = tid & 15u, g = tid >> 4;
+    // window sample 64 n + 32 s + 8 g: slot = that + 8 * (n + (32 s + 8 g) / 64) = 72 n + 32 s + 8 g  (32 s + 8 g < 64 only
+    // for s < 2: the pad of the NEXT 64-block comes in with s >= 2)
+    const _Float16 *bre = pl_re + 72u * n + 8u * g;
+    const _Float16 *bim = pl_im + 72u * n + 8u * g;
+    const h8 *af = a_img + tid;
+    f4x zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < kF2KS; ++s) {
+        // (32 s + 8 g) / 64 depends on g only when 32 s + 8 g crosses a multiple of 64: it does not (32 s is a multiple
+        //  of 32, 8 g <= 24), so the pad count is (32 s) / 64 = s / 2 for every lane
+        const h8 xr = *reinterpret_cast<const h8 *>(bre + 32 * s + 8 * (s >> 1));
+        const h8 xi = *reinterpret_cast<const h8 *>(bim + 32 * s + 8 * (s >> 1));
+        const h8 a0 = af[(s * 2 + 0) * 64];
+        const h8 a1 = af[(s * 2 + 1) * 64];
+        are = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xr, (FIRST && s == 0) ? zero : are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xi, (FIRST && s == 0) ? zero : aim, 0, 0, 0);
+        are = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xr, are, 0, 0, 0);
+        aim = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xi, aim, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __noinline__ void f2_fetch_image(const void *image, unsigned char *smem, uint32_t tid) {
+    v4u *dst = reinterpret_cast<v4u *>(smem) + tid;
+    const gptr128 src = reinterpret_cast<gptr128>((gbytes)image) + tid;
+    for (int i = 0; i < 2 * kF2KS; i += 2) {
+        const v4u f0 = src[64 * i], f1 = src[64 * i + 64];
+        dst[64 * i] = f0;
+        dst[64 * i + 64] = f1;
+    }
+}
+
+__global__ __launch_bounds__(64 * kF2Waves) __attribute__((amdgpu_waves_per_eu(4)))
+void fir2_mfma_kernel(const FrontParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t tid = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t cap = blockIdx.y;
+    MfmaTileCtx c;
+    c.rs.src = (gptr32)(reinterpret_cast<const uint32_t *>(p.iq) + (uint64_t)cap * p.cap_stride);
+    c.rs.halo = (gptr32)reinterpret_cast<const uint32_t *>(p.halo);
+    c.rs.halo_len = p.halo_len;
+    c.rs.n_valid = p.n_valid;
+    c.ctl = reinterpret_cast<uint32_t *>(smem_raw + kF2ImgBytes);
+    c.tickets = p.mfma_g * (uint32_t)kF2Waves;
+    c.tile_base = p.tile_base;
+    c.tile_end = p.tile_end;
+    c.aligned16 = (((uintptr_t)c.rs.src & 15u) == 0);
+    F2Taps ft;
+    ft.taps1 = (gptrf)(p.taps + p.stage[0].tap_off);
+    ft.taps2 = (gptrf)(p.taps + p.stage[1].tap_off);
+    ft.n1 = p.stage[0].ntaps;
+    ft.n2 = p.stage[1].ntaps;
+    typedef __attribute__((address_space(1))) uint64_t *gptr64;
+    typedef __attribute__((address_space(1))) uint32_t *gptr32w;
+    const gptr64 words = (gptr64)(p.bits + (uint64_t)cap * p.words_per_cap);
+    const gptr32w tile_info = (gptr32w)(p.tile_info + (uint64_t)cap * p.tiles_per_cap);
+    const h8 *a_img = reinterpret_cast<const h8 *>(smem_raw);
+    unsigned char *win = smem_raw + kF2ImgBytes + kMfmaCtlBytes + wave * kF2WaveBytes;
+    _Float16 *pl_re = reinterpret_cast<_Float16 *>(win);
+    _Float16 *pl_im = pl_re + kF2Plane;
+    typedef __attribute__((address_space(1))) v2fm *gptrf2;
+    const gptrf2 fout = p.fir_out ? (gptrf2)(reinterpret_cast<v2fm *>(p.fir_out) + (uint64_t)cap * p.n_out) : (gptrf2)nullptr;
+
+    if (threadIdx.x == 0) {
+        c.ctl[0] = 0;
+        c.ctl[1] = 0;
+    }
+    __syncthreads();
+
+    uint64_t tile = 0;
+    if (!mfma_take_ticket(c, tid, tile)) return;
+    uint4 q[kF2Rounds];
+    if (f2_interior(c, tile)) f2_issue_loads(c, tile, tid, q);
+    else f2_boundary_loads(c, tile, tid, win, q);
+    for (;;) {
+        asm volatile("" : "+v"(tid));
+        const uint32_t n = tid & 15u, g = tid >> 4;
+        const uint64_t M0 = tile * kF2Out;
+        v2s mx = (v2s){0, 0}, mn = (v2s){0, 0};
+#pragma unroll
+        for (int i = 0; i < kF2Rounds; ++i) {
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2sm(q[i].x), as_v2sm(q[i].y)));
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(as_v2sm(q[i].z), as_v2sm(q[i].w)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2sm(q[i].x), as_v2sm(q[i].y)));
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(as_v2sm(q[i].z), as_v2sm(q[i].w)));
+        }
+        const int L = p.quiet_lsb;
+        const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
+        const bool quiet = (!fout && __ballot(loud) == 0) || (p.mfma_debug & 1u);
+        const bool wide = __ballot(mx.x > 2047 || mx.y > 2047 || mn.x < -2048 || mn.y < -2048) != 0;
+
+        uint64_t tile_n = 0;
+        bool more = false, pre = false;
+        if (quiet) {
+            more = mfma_take_ticket(c, tid, tile_n);
+            pre = more && f2_interior(c, tile_n);
+            if (pre) f2_issue_loads(c, tile_n, tid, q);
+            if (!p.sparse) {
+                if (tid < kF2Out / 64) *reinterpret_cast<gptr64>(uniform_ptr((gbytes_w)(words + (M0 >> 6))) + 8u * tid) = 0;
+                if (tid == 0) *uniform_ptr(tile_info + tile) = 0;
+            }
+            if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + ((blockIdx.x * kF2Waves + wave) % kQuietCounters), 1u);
+        } else {
+            if (__hip_atomic_load(&c.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+                f2_fetch_image(p.mfma_a, smem_raw, tid);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) __hip_atomic_store(&c.ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            f4x are, aim;
+            if (!wide) {
+                f2_convert(q, 0xffffffffu, tid, pl_re, pl_im);
+                more = mfma_take_ticket(c, tid, tile_n);
+                pre = more && f2_interior(c, tile_n);
+                if (pre) f2_issue_loads(c, tile_n, tid, q);
+                f2_ksteps<true>(a_img, pl_re, pl_im, tid, are, aim);
+            } else {
+                f2_convert(q, 0xffe0ffe0u, tid, pl_re, pl_im);
+                f2_ksteps<true>(a_img, pl_re, pl_im, tid, are, aim);
+                f2_convert(q, 0x001f001fu, tid, pl_re, pl_im);
+                more = mfma_take_ticket(c, tid, tile_n);
+                pre = more && f2_interior(c, tile_n);
+                if (pre) f2_issue_loads(c, tile_n, tid, q);
+                f2_ksteps<false>(a_img, pl_re, pl_im, tid, are, aim);
+            }
+            // ---- power, threshold, guard band: register r of lane (n, g) is output 16 n + 4 g + r ------------
+            const float plo = wide ? p.p_lo_w : p.p_lo_n;
+            const float phi = wide ? p.p_hi_w : p.p_hi_n;
+            const uint32_t o_lane = 16u * n + 4u * g;
+            uint32_t nib = 0, unsure = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rr = are[r] * are[r], ii = aim[r] * aim[r];
+                const float pw = rr + ii;
+                const bool hi = pw >= phi;
+                nib |= (hi ? 1u : 0u) << r;
+                unsure |= ((!hi && pw >= plo) ? 1u : 0u) << r;
+            }
+            if (__ballot(unsure != 0) != 0) {
+                uint32_t todo = unsure, redo = 0;
+                while (todo) {
+                    const uint32_t r = (uint32_t)__ffs((int)todo) - 1u;
+                    todo &= todo - 1u;
+                    const uint64_t o = M0 + o_lane + r;
+                    if (o >= p.n_out) continue;
+                    const float2 y = fir2_mfma_exact_output(c.rs, ft, (int64_t)o);
+                    const float rr = y.x * y.x, ii = y.y * y.y;
+                    const float pe = rr + ii;
+                    nib = (nib & ~(1u << r)) | ((pe >= p.p_star ? 1u : 0u) << r);
+                    redo++;
+                }
+                if (redo && p.recompute_count) atomicAdd(p.recompute_count, (unsigned long long)redo);
+            }
+            if (fout) {
+                const float cs = p.mfma_c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t o = M0 + o_lane + r;
+                    if (o < p.n_out) fout[o] = (v2fm){are[r] * cs, aim[r] * cs};
+                }
+            }
+            // outputs past the end of the (padded) capture do not exist
+            if (M0 + o_lane + 4u > p.n_out) {
+                const uint32_t keep = M0 + o_lane >= p.n_out ? 0u : (uint32_t)(p.n_out - (M0 + o_lane));
+                nib &= (1u << keep) - 1u;
+            }
+            // ---- the tile's four 64-bit words: lane (n, g) holds bits 16 (n & 3) + 4 g .. + 3 of word n >> 2 ------
+            uint64_t w64 = (uint64_t)nib << (16u * (n & 3u) + 4u * g);
+#pragma unroll
+            for (int d = 1; d <= 32; d <<= 1) {
+                if (d == 4 || d == 8) continue;         // lanes that differ in n >> 2 hold other words
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)w64, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(w64 >> 32), d);
+                w64 |= (uint64_t)lo | ((uint64_t)hi << 32);
+            }
+            // level changes inside the tile (the tile's first bit against the tile before NOT included)
+            {
+                const uint32_t wq = n >> 2;                                     // this lane's word
+                const uint32_t top_prev = (uint32_t)__shfl((int)(uint32_t)(w64 >> 63), (int)((wq ? wq - 1u : 0u) << 2));   // lane 4 (wq - 1)
+                uint64_t ch = w64 ^ ((w64 << 1) | (wq ? (uint64_t)(top_prev & 1u) : 0ull));
+                if (wq == 0) ch &= ~1ull;
+                uint32_t cnt = ((n & 3u) == 0 && g == 0) ? (uint32_t)__popcll(ch) : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w64 & 1ull));
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w64 >> 63), 12);
+                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+            }
+            if ((n & 3u) == 0 && g == 0) {
+                const gbytes_w wb = uniform_ptr((gbytes_w)(words + (M0 >> 6)));
+                *reinterpret_cast<gptr64>(wb + 2u * n) = w64;           // word n >> 2 at byte 8 (n >> 2) = 2 n
+            }
+        }   // loud tile
+
+        if (!more) break;
+        if (!pre) f2_boundary_loads(c, tile_n, tid, win, q);
+        tile = tile_n;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 
@@ -627,6 +959,81 @@ bool mfma_prepare_taps(const float *taps, uint32_t ntaps, MfmaTaps &out) {
     return true;
 }
 
+// Two decimate-by-2 stages folded into one decimate-by-4 filter g (see fir2_mfma_kernel): pieces, image, residue.
+bool mfma_prepare_taps2(const float *taps1, uint32_t n1, const float *taps2, uint32_t n2, MfmaTaps &out) {
+    out = MfmaTaps();
+    if (n1 == 0 || n2 == 0 || n1 > 16 || n2 > 32) return false;
+    const uint32_t ng = 2 * (n2 - 1) + n1;                      // <= 78
+    std::vector<double> g(ng, 0.0), gabs(ng, 0.0);
+    for (uint32_t k2 = 0; k2 < n2; ++k2) {
+        for (uint32_t k1 = 0; k1 < n1; ++k1) {
+            if (!std::isfinite(taps1[k1]) || !std::isfinite(taps2[k2])) return false;
+            g[2 * k2 + k1] += (double)taps2[k2] * (double)taps1[k1];            // exact products; the sums round at 2^-53
+            gabs[2 * k2 + k1] += std::fabs((double)taps2[k2] * (double)taps1[k1]);
+        }
+    }
+    double gmax = 0.0, sum_abs = 0.0;
+    for (uint32_t t = 0; t < ng; ++t) {
+        gmax = std::max(gmax, std::fabs(g[t]));
+        sum_abs += gabs[t];
+    }
+    if (!(gmax > 0.0)) return false;
+    int e = 0;
+    (void)std::frexp(gmax, &e);
+    const int sh = 15 - e;
+    if (sh > 100 || sh < -100) return false;
+    const double S = std::ldexp(1.0, sh);
+    const double kMinNormal = std::ldexp(1.0, -14);
+    std::vector<_Float16> p1(ng), p2(ng);
+    double delta = 0.0, sum_hat = 0.0;
+    for (uint32_t t = 0; t < ng; ++t) {
+        const double hs = g[t] * S;
+        _Float16 a = (_Float16)hs;
+        if (std::fabs((double)a) < kMinNormal) a = (_Float16)0.0;
+        const double r1 = hs - (double)a;
+        _Float16 b = (_Float16)r1;
+        if (std::fabs((double)b) < kMinNormal) b = (_Float16)0.0;
+        const double r2 = r1 - (double)b;
+        if (!std::isfinite((double)a) || !std::isfinite((double)b)) return false;
+        p1[t] = a;
+        p2[t] = b;
+        delta += std::fabs(r2) / S + gabs[t] * std::ldexp(1.0, -50);       // (+ the double rounding of the fold)
+        sum_hat += std::fabs((double)a + (double)b) / S;
+    }
+    out.ksteps = (uint32_t)kF2KS;
+    out.image.assign((size_t)kF2KS * 2 * 64 * 8, 0);
+    for (int s = 0; s < kF2KS; ++s) {
+        for (int pc = 0; pc < 2; ++pc) {
+            for (uint32_t l = 0; l < 64; ++l) {
+                const uint32_t i = l & 15u, q = l >> 4;
+                for (uint32_t j = 0; j < 8; ++j) {
+                    const int64_t kk = 32 * s + 8 * (int64_t)q + j;
+                    const int64_t t = 4 * (int64_t)i + 99 - kk;
+                    _Float16 v = (_Float16)0.0;
+                    if (t >= 0 && t < (int64_t)ng) v = pc == 0 ? p1[t] : p2[t];
+                    out.image[(((size_t)s * 2 + pc) * 64 + l) * 8 + j] = half_bits(v);
+                }
+            }
+        }
+    }
+    out.c = (float)std::ldexp(1.0, -11 - sh);
+    out.delta = delta;
+    out.sum_abs = sum_abs;
+    out.sum_hat = sum_hat;
+    return true;
+}
+
+// forward bound on |y_mfma - y_ref| per component for the folded two-stage filter: `e_ref` = what the two-stage
+// reference chain may differ from real arithmetic by (rx.cpp: guard_error, for samples up to x_max), plus the
+// accumulation here and the residue of the pieces
+double mfma_error_bound2(const MfmaTaps &t, double e_ref, bool wide) {
+    const double u = std::ldexp(1.0, -24);
+    const double xmax = wide ? 16.0 : 1.0;
+    const double chain = (double)t.ksteps * 32.0 * 2.0 * (wide ? 2.0 : 1.0);
+    const double e_acc = chain * 2.0 * u * t.sum_hat;
+    return 1.1 * (e_ref + (e_acc + t.delta) * xmax) + 78.0 * std::ldexp(1.0, -140);
+}
+
 double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide) {
     // |y_mfma - y_ref| per component, x in units of 1 (= 2048 LSB):
     //   reference chain against the real sum: (T + 1) u sum|h| xmax   (T products, T sums)
@@ -663,11 +1070,37 @@ bool front_uses_mfma(const FrontParams &p) {
            mfma_ksteps_for(p.stage[0].ntaps) != 0;
 }
 
+bool front_uses_mfma2(const FrontParams &p) {
+    return p.mfma_a != nullptr && p.num_stages == 2 && !p.iq_f32 && !p.halo_f32 && p.stage[0].decim == 2 &&
+           p.stage[1].decim == 2 && p.stage[0].ntaps <= 16 && p.stage[1].ntaps <= 32 && p.origin % 4 == 0;
+}
+
+hipError_t launch_front_mfma2(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
+                              hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count) {
+    const uint64_t all = (p.n_out + kF2Out - 1) / kF2Out;
+    const uint64_t b = tile_begin < all ? tile_begin : all;
+    const uint64_t cnt = tile_count < all - b ? tile_count : all - b;
+    if (cnt == 0) return hipSuccess;
+    FrontParams pp = p;
+    pp.tile_base = (uint32_t)b;
+    pp.tile_end = b + cnt;
+    if (pp.mfma_g == 0) pp.mfma_g = 1;
+    const uint64_t grid = (cnt + (uint64_t)pp.mfma_g * kF2Waves - 1) / ((uint64_t)pp.mfma_g * kF2Waves);
+    const void *fn = reinterpret_cast<const void *>(&fir2_mfma_kernel);
+    hipError_t e = ensure_dynamic_lds(fn, kF2LdsBytes);
+    if (e != hipSuccess) return e;
+    void *args[] = {&pp};
+    e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kF2Waves), args, kF2LdsBytes, stream, t0, t1, 0);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 template <int KS>
 static hipError_t launch_mfma_ks(FrontParams &pp, uint32_t num_captures, uint64_t grid, hipStream_t stream,
                                  hipEvent_t t0, hipEvent_t t1) {
     const void *fn = reinterpret_cast<const void *>(&fir1_mfma_kernel<KS>);
-    const size_t lds = mfma_lds_bytes<KS>();
+    // (experiment: OOKD_MFMA_LDS_PAD caps the workgroups per CU, leaving registers / wave slots to other streams' kernels)
+    static const size_t lds_pad = dev_getenv("OOKD_MFMA_LDS_PAD") ? (size_t)atoi(dev_getenv("OOKD_MFMA_LDS_PAD")) : 0;
+    const size_t lds = mfma_lds_bytes<KS>() + lds_pad;
     hipError_t e = ensure_dynamic_lds(fn, lds);
     if (e != hipSuccess) return e;
     void *args[] = {&pp};

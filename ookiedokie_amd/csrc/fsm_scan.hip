@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
 }
 
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
-__global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
+__global__ __launch_bounds__(kSimThreads) __attribute__((amdgpu_waves_per_eu(4))) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
     copy_ltab(T, sp.ltab);

@@ -1292,6 +1292,9 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
         e = hipExtLaunchKernel(fn, dim3((uint32_t)grid, num_captures), dim3(64 * kFirWgWaves), args, lds_req, stream, t0, t1, 0);
         return e != hipSuccess ? e : hipGetLastError();
     }
+    if (use_fir2(p) && front_uses_mfma2(p) && !exact) {
+        return launch_front_mfma2(p, num_captures, stream, t0, t1, tile_begin, tile_count);
+    }
     if (use_fir2(p)) {
         const size_t lds = (size_t)kFir2Waves * Fir2Dec4::wave_bytes;
         range((p.n_out + (uint64_t)kFir2Waves * Fir2Dec4::F - 1) / ((uint64_t)kFir2Waves * Fir2Dec4::F), grid, pp);

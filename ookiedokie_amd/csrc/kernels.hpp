@@ -134,6 +134,12 @@ double mfma_error_bound(const MfmaTaps &t, uint32_t ntaps, bool wide);
 // a band edge in accumulator units (p / c^2); false when the scaling is not exact in float
 bool mfma_scale_band(const MfmaTaps &t, float p, float &out);
 bool front_uses_mfma(const FrontParams &p);
+// two decimate-by-2 stages (<= 16 and <= 32 taps) folded into one decimate-by-4 product (fir2_mfma_kernel)
+bool mfma_prepare_taps2(const float *taps1, uint32_t n1, const float *taps2, uint32_t n2, MfmaTaps &out);
+double mfma_error_bound2(const MfmaTaps &t, double e_ref, bool wide);
+bool front_uses_mfma2(const FrontParams &p);
+hipError_t launch_front_mfma2(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
+                              hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count);
 hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStream_t stream, hipEvent_t t0,
                              hipEvent_t t1, uint64_t tile_begin, uint64_t tile_count);
 

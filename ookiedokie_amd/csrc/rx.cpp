@@ -118,6 +118,7 @@ float power_threshold(float thr) {
 // sum|h_{s+1}|, and add their own rounding difference on values bounded by
 // 16 * prod sum|h|:  e = 2.2 u * 16 * prod_s S_s * sum_s (T_s + 1).
 void band_from_error(double e, float p_star, float &p_lo, float &p_hi);
+double guard_error(const std::vector<std::vector<float>> &stages, double x_max);
 void guard_band(const std::vector<std::vector<float>> &stages, float p_star, float &p_lo, float &p_hi) {
     if (std::isnan(p_star) || std::isinf(p_star) || p_star <= 0.0f) {
         p_lo = p_hi = p_star;
@@ -134,6 +135,20 @@ void guard_band(const std::vector<std::vector<float>> &stages, float p_star, flo
     }
     const double e = 2.2 * T * u * S * 16.0 * (stages.size() > 1 ? 1.01 : 1.0) + Tsum * std::ldexp(1.0, -140);
     band_from_error(e, p_star, p_lo, p_hi);
+}
+
+// the same bound for samples up to x_max (in units of 2048 LSB) instead of 16
+double guard_error(const std::vector<std::vector<float>> &stages, double x_max) {
+    const double u = std::ldexp(1.0, -24);
+    double S = 1.0, T = 0.0, Tsum = 0.0;
+    for (const auto &taps : stages) {
+        double ss = 0.0;
+        for (float t : taps) ss += std::fabs((double)t);
+        S *= std::max(ss, 1.0);
+        T += (double)taps.size() + 1.0;
+        Tsum += (double)taps.size();
+    }
+    return 2.2 * T * u * S * x_max * (stages.size() > 1 ? 1.01 : 1.0) + Tsum * std::ldexp(1.0, -140);
 }
 
 // [p_lo, p_hi) around p_star for a filter output known to within e per component
@@ -1468,6 +1483,18 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         // caller asks for the packed-VALU loop (or for the experimental streaming form, which only exists for it)
         MfmaTaps mt;
         bool use_mfma = false;
+        if (rx->num_stages == 2 && rx->stage[0].decim == 2 && rx->stage[1].decim == 2 && !(cfg->flags & OOKD_RX_FIR_VALU) &&
+            !dev_getenv("OOKD_FIR_VALU") &&
+            mfma_prepare_taps2(filter->stages[0].taps.data(), rx->stage[0].ntaps, filter->stages[1].taps.data(),
+                               rx->stage[1].ntaps, mt)) {
+            // the backend default shape (two decimate-by-2 stages) folded into one decimate-by-4 product
+            float lo_n, hi_n, lo_w, hi_w;
+            band_from_error(mfma_error_bound2(mt, guard_error(st, 1.0), false), rx->p_star, lo_n, hi_n);
+            band_from_error(mfma_error_bound2(mt, guard_error(st, 16.0), true), rx->p_star, lo_w, hi_w);
+            use_mfma = mfma_scale_band(mt, lo_n, rx->p_lo_n) && mfma_scale_band(mt, hi_n, rx->p_hi_n) &&
+                       mfma_scale_band(mt, lo_w, rx->p_lo_w) && mfma_scale_band(mt, hi_w, rx->p_hi_w);
+            if (rx->p_star > 0.0f && !(rx->p_star >= 0x1p-100f && rx->p_star <= 0x1p100f)) use_mfma = false;
+        }
         if (rx->num_stages == 1 && rx->stage[0].decim == 1 && !(cfg->flags & OOKD_RX_FIR_VALU) &&
             !dev_getenv("OOKD_FRONT_STREAM") && !dev_getenv("OOKD_FIR_VALU") &&
             mfma_prepare_taps(filter->stages[0].taps.data(), rx->stage[0].ntaps, mt)) {

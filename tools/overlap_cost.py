@@ -13,8 +13,8 @@ def name(r):
     return r['Kernel_Name'].split('(')[0].replace('void ', '').replace('ookd::', '').split('<')[0]
 ks = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), name(r)) for r in rows]
 ks.sort()
-front = [k for k in ks if k[2].startswith('fir1_bits')]
-others = [k for k in ks if not k[2].startswith('fir1_bits') and not k[2].startswith('__amd') and not k[2].startswith('synth')]
+front = [k for k in ks if k[2].startswith('fir1_')]
+others = [k for k in ks if not k[2].startswith('fir1_') and not k[2].startswith('__amd') and not k[2].startswith('synth')]
 names = sorted(set(k[2] for k in others))
 # steady state only: drop the first and last 15 % of the front-end launches
 lo, hi = int(len(front) * 0.15), int(len(front) * 0.85)
