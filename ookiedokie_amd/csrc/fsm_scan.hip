@@ -2107,55 +2107,61 @@ __global__ __launch_bounds__(kSimThreads) __attribute__((amdgpu_waves_per_eu(4))
     if (*sp.fallback) return;
     const uint32_t LB = sp.leaf_block;
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
-    // work items: every block, then one "ends" item per capture (first span + tail)
-    for (uint32_t w = blockIdx.x; w < total + sp.f.num_captures; w += gridDim.x) {
-        if (w < total) {
-            uint32_t cap, lb;
-            locate_block(sp, w, cap, lb);
-            uint64_t e0;
-            const uint64_t ne = cap_edges(sp.f, cap, e0);
-            const uint64_t *edges = sp.f.edges + e0;
-            LeafEvDev *events = sp.events + e0 + cap;
-            const uint64_t first = 1 + (uint64_t)lb * LB;
-            const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
-            // The leaves' entry codes are there already (scan_entry_kernel): no table is staged, nothing goes through
-            // the LDS, no barrier -- every lane asks for its leaf's code and its two edges at once (one round trip to
-            // memory per block; the four waves ask for the same 64 leaves, which the cache absorbs), then a wavefront
-            // takes the leaves entered in "its" states (state mod 4; skip and poison codes form row S), so that its
-            // lanes run the same triggers.
-            const uint32_t nwaves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-            for (uint32_t l = threadIdx.x & 63u; l < count; l += 64) {
-                const uint64_t i = first + l;
-                uint32_t in = sp.pre_codes[(size_t)w * LB + l];
-                const uint64_t e_before = edges[i - 1], e_at = edges[i];
-                if ((in / T.NB1) % nwaves != wave) continue;
-                PSim f;
-                Acc a;
-                bool alive = true;
-                if (in == code_poison(T)) {
-                    scan_refuse(sp, cap, (uint32_t)kFbPoison);
-                    acc_init(a);
-                    f.cur = f.nbits = f.k = f.prev = 0;
-                } else {
-                    Span span;
-                    span.pos0 = e_before + 1;
-                    span.n = e_at - e_before - 1;
-                    span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
-                    span.has_edge = true;
-                    span.prefix = 0;
-                    if (in >= T.S * T.NB1 + 3) {            // entered stuck: from where the state was normal (span_entered)
-                        uint32_t d, src;
-                        stuck_decode(T, in, d, src);
-                        span.prefix = e_before - edges[i - d - 1];
-                        in = src;
+    // work items: groups of FOUR blocks, then one "ends" item per capture (first span + tail).
+    // A workgroup takes four blocks = 256 leaves, one per lane: waves 0 / 1 the even / odd leaves of blocks 0 and 1,
+    // waves 2 / 3 those of blocks 2 and 3 -- leaves of one parity run at one level, so a wave's lanes sit in the
+    // same few states and run the same triggers, and every lane has a leaf.  (Round 2 gave a workgroup ONE block
+    // and each of its four waves the leaves entered in "its" states: a quarter of the lanes busy, four times the
+    // workgroup rounds -- 130 us per 16 GiB capture.)
+    const uint32_t nquad = (total + 3u) / 4u;
+    for (uint32_t wq = blockIdx.x; wq < nquad + sp.f.num_captures; wq += gridDim.x) {
+        if (wq < nquad) {
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+            const uint32_t w = 4u * wq + 2u * (wave >> 1) + (lane >> 5);
+            const uint32_t l = 2u * (lane & 31u) + (wave & 1u);
+            if (w < total) {
+                uint32_t cap, lb;
+                locate_block(sp, w, cap, lb);
+                uint64_t e0;
+                const uint64_t ne = cap_edges(sp.f, cap, e0);
+                const uint64_t *edges = sp.f.edges + e0;
+                LeafEvDev *events = sp.events + e0 + cap;
+                const uint64_t first = 1 + (uint64_t)lb * LB;
+                const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+                // The leaves' entry codes are there already (scan_entry_kernel): no table is staged, nothing goes
+                // through the LDS, no barrier -- every lane asks for its leaf's code and its two edges at once.
+                if (l < count) {
+                    const uint64_t i = first + l;
+                    uint32_t in = sp.pre_codes[(size_t)w * LB + l];
+                    const uint64_t e_before = edges[i - 1], e_at = edges[i];
+                    PSim f;
+                    Acc a;
+                    bool alive = true;
+                    if (in == code_poison(T)) {
+                        scan_refuse(sp, cap, (uint32_t)kFbPoison);
+                        acc_init(a);
+                        f.cur = f.nbits = f.k = f.prev = 0;
+                    } else {
+                        Span span;
+                        span.pos0 = e_before + 1;
+                        span.n = e_at - e_before - 1;
+                        span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
+                        span.has_edge = true;
+                        span.prefix = 0;
+                        if (in >= T.S * T.NB1 + 3) {            // entered stuck: from where the state was normal (span_entered)
+                            uint32_t d, src;
+                            stuck_decode(T, in, d, src);
+                            span.prefix = e_before - edges[i - d - 1];
+                            in = src;
+                        }
+                        alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
+                        if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                     }
-                    alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
-                    if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
+                    write_event(events[i], a, f, alive);
                 }
-                write_event(events[i], a, f, alive);
             }
         } else {
-            const uint32_t cap = w - total;
+            const uint32_t cap = wq - nquad;
             uint64_t e0;
             const uint64_t ne = cap_edges(sp.f, cap, e0);
             const uint64_t *edges = sp.f.edges + e0;
