@@ -239,9 +239,6 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
     if (b >= total_blocks) return;
-    const uint32_t off = p.blk_offset[b] + p.group_total[b / kScanGroup];
-    p.blk_offset[b] = off;
-    if (p.blk_count[b] == 0) return;
     const uint32_t cap = b / p.blocks_per_cap, blk = b - cap * p.blocks_per_cap;
     constexpr uint32_t tpb = TPB;           // wave tiles per 4096-bit block: 4, 8 or 16 (compile time: everything unrolls)
     constexpr uint32_t words_per_tile = (uint32_t)kBlockWords / tpb;
@@ -249,10 +246,13 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
     const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     const uint32_t t0 = blk * tpb;
-    // Few round trips to memory per lane (the kernel is latency times rounds of waves): the block's tile infos in
-    // one go (4, 8 or 16 dwords = 1, 2 or 4 16-byte loads), then every loud tile's words in one go (64 bytes).
+    // Few round trips to memory per lane (the kernel is latency times rounds of waves): the block's offset, count AND
+    // tile infos (4, 8 or 16 dwords = 1, 2 or 4 16-byte loads) in ONE go -- the infos of a block without an edge
+    // are 16 MB per 16 GiB capture read for nothing, and one dependent round trip less for every block that has
+    // one --, then every loud tile's words in one go (64 bytes).
     uint32_t infos[tpb];
     {
+        const uint32_t off_local = p.blk_offset[b], gbase = p.group_total[b / kScanGroup], cnt = p.blk_count[b];
         const uint32_t prev_info = (t0 || p.has_prev) ? *(ti + t0 - 1) : 0u;
         const uint4 *ti4 = reinterpret_cast<const uint4 *>(ti + t0);
 #pragma unroll
@@ -263,6 +263,9 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
             infos[4 * q + 2] = v.z;
             infos[4 * q + 3] = v.w;
         }
+        const uint32_t off = off_local + gbase;
+        p.blk_offset[b] = off;
+        if (cnt == 0) return;
         uint32_t prev_last = (t0 || p.has_prev) ? tile_live(prev_info, p.stamp_bits) >> 31 : 0u;
         uint64_t at = off;
 #pragma unroll

@@ -520,7 +520,9 @@ struct ScanParams {
     uint32_t S;                 // machine states
     uint32_t *cap_group_off;    // [captures + 1] prefix of group counts
     uint16_t *group_tab;        // [groups][Dp]
-    uint16_t *group_in;         // [groups]
+    uint32_t *cap_super_off;    // [captures + 1] prefix of supergroup counts (a supergroup = kSuper groups)
+    uint16_t *super_tab;        // [supergroups][Dp]
+    uint16_t *super_in;         // [supergroups] entry code (scan_walk_kernel)
     uint16_t *cap_end;          // [captures] state after the last regular leaf
     uint16_t *cap_first;        // [captures] state after the first span (leaf kernel -> walk kernel)
 };
@@ -1291,7 +1293,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
     const uint32_t nc = sp.f.num_captures;
     const uint32_t chunk = (nc + kScanThreads - 1) / kScanThreads;
     const uint32_t lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
-    uint32_t sum = 0, sum2 = 0, sum3 = 0;
+    uint32_t sum = 0, sum2 = 0, sum3 = 0, sum4 = 0;
     for (uint32_t c = lo; c < hi; ++c) {
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, c, e0);
@@ -1300,15 +1302,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
         sum += nblk;
         sum2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
         sum3 += (nblk + 15u) / 16u;
+        sum4 += (nblk + 63u) / 64u;
     }
-    uint32_t tot = 0, tot2 = 0, tot3 = 0;
+    uint32_t tot = 0, tot2 = 0, tot3 = 0, tot4 = 0;
     uint32_t run = wg_inclusive_sum(sum, wtot, &tot) - sum;
     uint32_t run2 = wg_inclusive_sum(sum2, wtot, &tot2) - sum2;
     uint32_t run3 = wg_inclusive_sum(sum3, wtot, &tot3) - sum3;
+    uint32_t run4 = wg_inclusive_sum(sum4, wtot, &tot4) - sum4;
     for (uint32_t c = lo; c < hi; ++c) {
         sp.cap_block_off[c] = run;
         sp.fin_off[c] = run2;
         sp.cap_group_off[c] = run3;
+        sp.cap_super_off[c] = run4;
         uint64_t e0;
         const uint64_t ne = cap_edges(sp.f, c, e0);
         const uint64_t regular = ne > 1 ? ne - 1 : 0;
@@ -1316,11 +1321,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_layout_kernel(ScanParams sp
         run += nblk;
         run2 += (uint32_t)((ne + 1 + kFinBlock - 1) / kFinBlock);
         run3 += (nblk + 15u) / 16u;
+        run4 += (nblk + 63u) / 64u;
     }
     if (tid == kScanThreads - 1) {
         sp.cap_block_off[nc] = tot;
         sp.fin_off[nc] = tot2;
         sp.cap_group_off[nc] = tot3;
+        sp.cap_super_off[nc] = tot4;
         if (tot > sp.total_blocks_cap || tot2 > sp.fin_blocks_cap) atomicOr(sp.fallback, (uint32_t)kFbBlocks);
         // more level changes than the edge list holds: its tail was never written and the buffers
         // sized by the capacity would be overrun -- no scan (the host reports OOKD_ERR_CAPACITY)
@@ -1776,10 +1783,17 @@ __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
 }
 
 // Walk of the block tables from the true start state, three small kernels:
-// groups of 16 block tables are composed in parallel (one workgroup each),
-// one lane per capture walks the group tables, then one lane per group walks
-// its 16 blocks.
+// supergroups of 64 block tables are composed in parallel (one workgroup each:
+// four groups of 16, then the four group tables), one lane per capture walks
+// the supergroup tables, then (scan_entry_kernel, phase 0) one lane per group
+// walks the group tables in front of it in its supergroup and its 16 blocks.
+// (Round 2 stopped at the groups: the walk's one lane had 720 tables to go
+// through at 16 GiB, 128 staged at a time -- 47 us, every one of them on the
+// chain's critical path.)
 constexpr int kGroup = 16;              // block tables per group
+constexpr int kSuper = 4;               // groups per supergroup
+constexpr int kSuperBlocks = kGroup * kSuper;
+constexpr int kGroupsThreads = 1024;
 
 __device__ __forceinline__ void locate_group(const ScanParams &sp, uint32_t gg, uint32_t &cap, uint32_t &lg) {
     uint32_t lo = 0, hi = sp.f.num_captures;
@@ -1792,7 +1806,18 @@ __device__ __forceinline__ void locate_group(const ScanParams &sp, uint32_t gg, 
     lg = gg - sp.cap_group_off[lo];
 }
 
-// stage the block tables [b0, b0+nb) of one group into LDS
+__device__ __forceinline__ void locate_super(const ScanParams &sp, uint32_t ss, uint32_t &cap, uint32_t &ls) {
+    uint32_t lo = 0, hi = sp.f.num_captures;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sp.cap_super_off[mid] <= ss) lo = mid;
+        else hi = mid;
+    }
+    cap = lo;
+    ls = ss - sp.cap_super_off[lo];
+}
+
+// stage the block tables [b0, b0+nb) into LDS
 __device__ __forceinline__ void stage_group(const ScanParams &sp, uint32_t b0, uint32_t nb, uint16_t *stage) {
     const uint4 *src = reinterpret_cast<const uint4 *>(sp.block_tab + (size_t)b0 * sp.Dp);
     uint4 *dst = reinterpret_cast<uint4 *>(stage);
@@ -1800,22 +1825,36 @@ __device__ __forceinline__ void stage_group(const ScanParams &sp, uint32_t b0, u
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void scan_groups_kernel(ScanParams sp) {
+__host__ __device__ __forceinline__ size_t groups_lds_bytes(uint32_t Dp) { return (size_t)(kSuperBlocks + kSuper) * Dp * 2; }
+
+__global__ __launch_bounds__(kGroupsThreads) void scan_groups_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     if (*sp.fallback) return;
-    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kGroup][Dp]
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kSuperBlocks][Dp] block tables
+    uint16_t *gt = stage + (size_t)kSuperBlocks * sp.Dp;            // [kSuper][Dp] the group tables
     const uint32_t D = sp.D;            // the whole domain, stuck codes included
-    const uint32_t total = sp.cap_group_off[sp.f.num_captures];
-    for (uint32_t gg = blockIdx.x; gg < total; gg += gridDim.x) {
-        uint32_t cap, lg;
-        locate_group(sp, gg, cap, lg);
-        const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
-        const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
+    const uint32_t total = sp.cap_super_off[sp.f.num_captures];
+    for (uint32_t ss = blockIdx.x; ss < total; ss += gridDim.x) {
+        uint32_t cap, ls;
+        locate_super(sp, ss, cap, ls);
+        const uint32_t b0 = sp.cap_block_off[cap] + ls * kSuperBlocks;
+        const uint32_t nb = min((uint32_t)kSuperBlocks, sp.cap_block_off[cap + 1] - b0);
+        const uint32_t g0 = sp.cap_group_off[cap] + ls * kSuper;
+        const uint32_t ng = (nb + kGroup - 1) / kGroup;
         stage_group(sp, b0, nb, stage);
+        for (uint32_t item = threadIdx.x; item < ng * D; item += blockDim.x) {
+            const uint32_t j = item / D, d = item - j * D;
+            const uint32_t q0 = j * kGroup, q1 = min(q0 + (uint32_t)kGroup, nb);
+            uint32_t s = d;
+            for (uint32_t q = q0; q < q1; ++q) s = stage[q * sp.Dp + s];
+            gt[j * sp.Dp + d] = (uint16_t)s;
+            sp.group_tab[(size_t)(g0 + j) * sp.Dp + d] = (uint16_t)s;
+        }
+        __syncthreads();
         for (uint32_t d = threadIdx.x; d < D; d += blockDim.x) {
             uint32_t s = d;
-            for (uint32_t j = 0; j < nb; ++j) s = stage[j * sp.Dp + s];
-            sp.group_tab[(size_t)gg * sp.Dp + d] = (uint16_t)s;
+            for (uint32_t j = 0; j < ng; ++j) s = gt[j * sp.Dp + s];
+            sp.super_tab[(size_t)ss * sp.Dp + d] = (uint16_t)s;
         }
         __syncthreads();
     }
@@ -1825,16 +1864,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t x;
     if (*sp.fallback) return;
-    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 group tables at a time
+    uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 supergroup tables at a time
     const uint32_t max_stage = 128;
     for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
-        const uint32_t g0 = sp.cap_group_off[cap], g1 = sp.cap_group_off[cap + 1];
+        const uint32_t g0 = sp.cap_super_off[cap], g1 = sp.cap_super_off[cap + 1];
         if (threadIdx.x == 0) x = sp.cap_first[cap];        // from the leaf kernel
         __syncthreads();
         for (uint32_t gs = g0; gs < g1; gs += max_stage) {
             const uint32_t ng = min(max_stage, g1 - gs);
             {
-                const uint4 *src = reinterpret_cast<const uint4 *>(sp.group_tab + (size_t)gs * sp.Dp);
+                const uint4 *src = reinterpret_cast<const uint4 *>(sp.super_tab + (size_t)gs * sp.Dp);
                 uint4 *dst = reinterpret_cast<uint4 *>(stage);
                 for (uint32_t i = threadIdx.x; i < ng * (sp.Dp / 8); i += blockDim.x) dst[i] = src[i];
             }
@@ -1842,7 +1881,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) 
             if (threadIdx.x == 0) {
                 uint32_t s = x;
                 for (uint32_t g = 0; g < ng; ++g) {
-                    sp.group_in[gs + g] = (uint16_t)s;
+                    sp.super_in[gs + g] = (uint16_t)s;
                     s = stage[g * sp.Dp + s];
                 }
                 x = s;
@@ -1959,7 +1998,9 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
             locate_group(sp, gg, cap, lg);
             const uint32_t b0 = sp.cap_block_off[cap] + lg * kGroup;
             const uint32_t nb = min((uint32_t)kGroup, sp.cap_block_off[cap + 1] - b0);
-            uint32_t s = sp.group_in[gg];
+            // the group's entry state: its supergroup's, through the group tables in front of it
+            uint32_t s = sp.super_in[sp.cap_super_off[cap] + lg / kSuper];
+            for (uint32_t j = gg - (lg % kSuper); j < gg; ++j) s = sp.group_tab[(size_t)j * sp.Dp + s];
             for (uint32_t j = 0; j < nb; ++j) {
                 sp.blk_in[b0 + j] = (uint16_t)s;
                 s = sp.block_tab[(size_t)(b0 + j) * sp.Dp + s];
@@ -2028,44 +2069,46 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         const uint64_t *edges = sp.f.edges + e0;
         const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
         uint32_t s = sp.blk_in[gb];
-        // eight leaves at a time: their edges in one go (one memory latency per eight steps, not per step), their
-        // codes in one 16-byte store (block-major list: 2 * LB bytes per block, aligned).  Fast form: the eight row
-        // sets come from phase 2, a step is one read of the row the state selects plus its decode; a skip state
-        // whose buffer has not ended by the leaf's edge stays what it is; everything else takes the full step.
         uint4 *pre = reinterpret_cast<uint4 *>(sp.pre_codes + (size_t)gb * LB);
-        uint64_t before = edges[first - 1];
-        for (uint32_t l0 = 0; l0 < count; l0 += 8) {
-            uint64_t ev[8];
+        if (fast && LB == 64) {
+            // Fast form.  ONE round trip to memory for the whole block: the 64 leaves' row intervals (phase 2) and
+            // what the leaf kernel found for the two skip codes are requested together, before the first step; a
+            // step is then one LDS read of the row the state selects plus its decode.  The edges themselves are
+            // only read by a step that needs the full function (under one per cent of them).  (First form: eight
+            // leaves' edges, intervals and skip results per eight steps -- eight dependent round trips per block,
+            // 45 us for the pass at 16 GiB.)
+            const uint4 *z4p = reinterpret_cast<const uint4 *>(sp.rowz + (size_t)gb * LB);
+            const uint4 *sk4p = reinterpret_cast<const uint4 *>(sp.skipc + (size_t)gb * LB);
+            uint4 zq[8], skq[16];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) ev[k] = edges[first + min(l0 + k, count - 1)];
-            uint32_t roff[8], skp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (fast) {
-                const uint4 z4 = *reinterpret_cast<const uint4 *>(sp.rowz + (size_t)gb * LB + l0);
-                if (sp.skipc_valid) {
-                    const uint4 *sk4 = reinterpret_cast<const uint4 *>(sp.skipc + (size_t)gb * LB + l0);
-                    const uint4 s0 = sk4[0], s1 = sk4[1];
-                    skp[0] = s0.x; skp[1] = s0.y; skp[2] = s0.z; skp[3] = s0.w;
-                    skp[4] = s1.x; skp[5] = s1.y; skp[6] = s1.z; skp[7] = s1.w;
-                }
-                const uint32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
-                const uint32_t rows0 = 4 + g_mr[0] + g_mr[1], nbp0 = g_mr[0], twoS = 2u * T.S;
+            for (uint32_t q = 0; q < 8; ++q) zq[q] = z4p[q];
+            if (sp.skipc_valid) {
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) skq[q] = sk4p[q];
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) skq[q] = make_uint4(0, 0, 0, 0);
+            }
+            const uint32_t rows0 = 4 + g_mr[0] + g_mr[1], nbp0 = g_mr[0], twoS = 2u * T.S;
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) {
+                if (8 * g >= count) break;
+                const uint32_t zz[4] = {zq[g].x, zq[g].y, zq[g].z, zq[g].w};
+                const uint32_t sk[8] = {skq[2 * g].x, skq[2 * g].y, skq[2 * g].z, skq[2 * g].w,
+                                        skq[2 * g + 1].x, skq[2 * g + 1].y, skq[2 * g + 1].z, skq[2 * g + 1].w};
+                uint32_t code[8];
 #pragma unroll
                 for (uint32_t k = 0; k < 8; ++k) {
-                    const uint32_t z = (zz[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
-                    const uint32_t L = (uint32_t)((first + l0 + k) & 1ull) ^ T.lvl0;
-                    roff[k] = z != 0xffffu ? rows0 + ((L ? nbp0 : 0u) + z) * twoS : 0xffffffffu;
-                }
-            }
-            uint32_t code[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) {
-                code[k] = s;
-                if (l0 + k < count) {
-                    if (fast) {
+                    code[k] = s;
+                    const uint32_t l = 8 * g + k;
+                    if (l < count) {
+                        const uint32_t z = (zz[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
                         bool done = false;
-                        if (s < SNB && roff[k] != 0xffffffffu) {
+                        if (s < SNB && z != 0xffffu) {
+                            const uint32_t L = (uint32_t)((first + l) & 1ull) ^ T.lvl0;
+                            const uint32_t roff = rows0 + ((L ? nbp0 : 0u) + z) * twoS;
                             const uint32_t cur = __umulhi(s, rcpNB1), nb = s - cur * T.NB1;
-                            const uint32_t p = g_mr[roff[k] + 2u * cur + (nb >= T.max_bits ? 1u : 0u)];
+                            const uint32_t p = g_mr[roff + 2u * cur + (nb >= T.max_bits ? 1u : 0u)];
                             if (p & kPkAbsolute) {
                                 s = p & 0xffffu;
                                 done = true;
@@ -2074,19 +2117,40 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
                                 s = (p & 0xffu) * T.NB1 + (nbo >= T.NB1 ? T.NB1 - 1 : nbo);
                                 done = true;
                             }
-                        } else if (s >= SNB && s < SNB + 2) {
-                            if (sp.skipc_valid) {
-                                const uint32_t stored = (skp[k] >> (16u * (s - SNB))) & 0xffffu;
-                                s = stored;     // what the leaf kernel found for this leaf
-                                done = true;
-                            } else if (next_buffer_start(T, before) > ev[k]) {
-                                done = true;                                    // still skipping when the span ends
+                        } else if (s >= SNB && s < SNB + 2 && sp.skipc_valid) {
+                            s = (sk[k] >> (16u * (s - SNB))) & 0xffffu;     // what the leaf kernel found for this leaf
+                            done = true;
+                        }
+                        if (!done) {
+                            const uint64_t e_before = edges[first + l - 1], e_at = edges[first + l];
+                            if (s >= SNB && s < SNB + 2 && next_buffer_start(T, e_before) > e_at) {
+                                // still skipping when the span ends
+                            } else {
+                                s = leaf_step_fly_g(T, sc, noff, nint, first + l, e_before, e_at, s);
                             }
                         }
-                        if (!done) s = leaf_step_fly_g(T, sc, noff, nint, first + l0 + k, before, ev[k], s);
-                    } else {
-                        s = leaf_step_fly(T, sc, first + l0 + k, before, ev[k], s);
                     }
+                }
+                pre[g] = make_uint4(code[0] | (code[1] << 16), code[2] | (code[3] << 16), code[4] | (code[5] << 16),
+                                    code[6] | (code[7] << 16));
+            }
+            continue;
+        }
+        // General form (no tables in LDS, or blocks of another size): eight leaves at a time, their edges in one go
+        // (one memory latency per eight steps, not per step), their codes in one 16-byte store (block-major list:
+        // 2 * LB bytes per block, aligned).
+        uint64_t before = edges[first - 1];
+        for (uint32_t l0 = 0; l0 < count; l0 += 8) {
+            uint64_t ev[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) ev[k] = edges[first + min(l0 + k, count - 1)];
+            uint32_t code[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                code[k] = s;
+                if (l0 + k < count) {
+                    s = fast ? leaf_step_fly_g(T, sc, noff, nint, first + l0 + k, before, ev[k], s)
+                             : leaf_step_fly(T, sc, first + l0 + k, before, ev[k], s);
                     before = ev[k];
                 }
             }
@@ -3009,17 +3073,21 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.S = a.S;
     sp.cap_group_off = a.cap_group_off;
     sp.group_tab = a.group_tab;
-    sp.group_in = a.group_in;
+    sp.cap_super_off = a.cap_super_off;
+    sp.super_tab = a.super_tab;
+    sp.super_in = a.super_in;
     sp.cap_end = a.cap_end;
     sp.cap_first = a.cap_first;
     const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S, a.SNB);
-    const size_t lds_group = (size_t)kGroup * sp.Dp * 2;
+    const size_t lds_group = groups_lds_bytes(sp.Dp);
     const size_t lds_walk = (size_t)128 * sp.Dp * 2;
     if (lds_walk > 150u * 1024u) return hipErrorInvalidValue;
     hipError_t e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_leaf_kernel), lds);
     if (e != hipSuccess) return e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_walk_kernel), lds_walk);
+    if (e != hipSuccess) return e;
+    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_groups_kernel), lds_group);
     if (e != hipSuccess) return e;
     // with span tables and 64-leaf blocks the leaf kernel runs one wave per block (OOKD_SCAN_LEAF=block: the
     // workgroup-per-block form, which is also what runs without span tables)
@@ -3088,7 +3156,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     } else {
         hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
     }
-    hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(256), lds_group, stream, sp);
+    hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(kGroupsThreads), lds_group, stream, sp);
     hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
     // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables
     sp.pre_codes = a.pre_codes;

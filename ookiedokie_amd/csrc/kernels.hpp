@@ -372,7 +372,9 @@ struct FsmScanArgs {
     uint32_t fin_blocks_cap;
     uint32_t *cap_group_off;    // [captures + 1]
     uint16_t *group_tab;        // [total_blocks_cap / 16 + captures + 1][D rounded up to 8]
-    uint16_t *group_in;         // same count
+    uint32_t *cap_super_off;    // [captures + 1]
+    uint16_t *super_tab;        // [total_blocks_cap / 64 + captures + 1][D rounded up to 8]
+    uint16_t *super_in;         // same count
     uint16_t *cap_end;          // [captures]
     uint16_t *cap_first;        // [captures]
 };

@@ -420,8 +420,8 @@ struct ookd_rx {
     DevBuf<uint32_t> d_lt_merged;                    // build_merged_rows of them
     DevBuf<uint4> d_ltab;           // the scan kernels' LDS table image
     DevBuf<uint16_t> d_reach;       // abstract codes a span can be entered in (empty = all)
-    DevBuf<uint32_t> d_cap_group_off;
-    DevBuf<uint16_t> d_group_tab, d_group_in, d_cap_end;
+    DevBuf<uint32_t> d_cap_group_off, d_cap_super_off;
+    DevBuf<uint16_t> d_group_tab, d_super_tab, d_super_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
     DevBuf<uint8_t> d_app_vals;
@@ -504,7 +504,9 @@ struct ookd_rx {
         d_reach.release();
         d_cap_group_off.release();
         d_group_tab.release();
-        d_group_in.release();
+        d_super_tab.release();
+        d_super_in.release();
+        d_cap_super_off.release();
         d_cap_end.release();
         d_cap_block_off.release();
         d_events.release();
@@ -855,7 +857,9 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         }
         a.cap_group_off = d_cap_group_off.p;
         a.group_tab = d_group_tab.p;
-        a.group_in = d_group_in.p;
+        a.cap_super_off = d_cap_super_off.p;
+        a.super_tab = d_super_tab.p;
+        a.super_in = d_super_in.p;
         a.cap_end = d_cap_end.p;
         a.cap_first = d_cap_end.p + (max_captures + 8);
         a.cap_block_off = d_cap_block_off.p;
@@ -1160,7 +1164,9 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.publish = publish_params();
     a.cap_group_off = d_cap_group_off.p;
     a.group_tab = d_group_tab.p;
-    a.group_in = d_group_in.p;
+    a.cap_super_off = d_cap_super_off.p;
+    a.super_tab = d_super_tab.p;
+    a.super_in = d_super_in.p;
     a.cap_end = d_cap_end.p;
     a.cap_first = d_cap_end.p + (max_captures + 8);
     a.cap_block_off = d_cap_block_off.p;
@@ -1728,7 +1734,10 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                 const size_t ngroups = rx->scan_blocks_cap / 16 + caps + 8;
                 rc |= rx->d_cap_group_off.alloc(caps + 1);
                 rc |= rx->d_group_tab.alloc(ngroups * ((rx->scan_D + 7u) & ~7u) + 64);
-                rc |= rx->d_group_in.alloc(ngroups);
+                const size_t nsuper = rx->scan_blocks_cap / 64 + caps + 8;
+                rc |= rx->d_cap_super_off.alloc(caps + 1);
+                rc |= rx->d_super_tab.alloc(nsuper * ((rx->scan_D + 7u) & ~7u) + 64);
+                rc |= rx->d_super_in.alloc(nsuper);
                 rc |= rx->d_cap_end.alloc(2 * (caps + 8));         // + cap_first
             }
             rc |= rx->d_cap_block_off.alloc(caps + 1);
