@@ -182,7 +182,17 @@ enum {
      * fp16 pieces whose products are exact, fp32 accumulation, guard band +
      * exact recompute as in the fused form: identical bits, floats within 1e-5).
      * Set this for the packed-VALU loop instead (exists so the tests run both). */
-    OOKD_RX_FIR_VALU = 1u << 8
+    OOKD_RX_FIR_VALU = 1u << 8,
+    /* State machine scan: always compose the per-block transition tables.  By
+     * default the scan first looks for SYNCHRONISING spans -- stretches of
+     * constant level long enough that the machine ends them in one state
+     * whatever state it entered them in without an error (the silence between
+     * two messages) --, walks from each to the next taking that state for
+     * granted, and checks every such assumption with the walk that arrives
+     * there; the composing kernels only run for a capture where a check fails
+     * or no such span turns up within 512 edges.  Identical results; the flag
+     * exists so the tests can run both (stats.scan_entry_form). */
+    OOKD_RX_SCAN_TABLES = 1u << 9
 };
 
 /* Contexts created with the same gate (and on the same device) queue their front-end kernels one
@@ -258,6 +268,9 @@ typedef struct ookd_rx_stats {
     uint32_t pipeline_chunks;       /* chunks the run was pipelined in (0 = not pipelined) */
     uint32_t front_launches;        /* grid launches the front end went out as; fir_kernel_ms spans
                                        first start -> last end                */
+    uint32_t scan_entry_form;       /* how the scan found the leaves' entry states: 1 walk from
+                                       synchronising spans, 2 composed block tables, 0 no scan */
+    uint32_t reserved;
 } ookd_rx_stats;
 
 ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,

@@ -44,6 +44,7 @@ RX_SCAN_SIMS = 32
 RX_FRONT_GRID = 64
 RX_NO_PIPELINE = 128
 RX_FIR_VALU = 256
+RX_SCAN_TABLES = 512
 DEFAULT_THRESHOLD = 0.1                 # ookiedokie_cfg.c:27
 DEFAULT_RATE = 3000000                  # ookiedokie_cfg.c:32
 DEFAULT_SAMPLES_PER_BUF = 8192          # ookiedokie_cfg.c:34
@@ -111,6 +112,7 @@ class RxStats(C.Structure):
         ("fir_kernel_ms", C.c_float), ("total_device_ms", C.c_float),
         ("quiet_waves", C.c_uint64), ("total_waves", C.c_uint64),
         ("pipeline_chunks", C.c_uint32), ("front_launches", C.c_uint32),
+        ("scan_entry_form", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -539,14 +541,15 @@ class Receiver:
                  message_capacity: int = 0, stream: int = 0, fsm_rounds: bool = False,
                  quiet_skip: bool = True, count_quiet: bool = False, scan_sims: bool = False,
                  front_grid: bool = False, pipeline: bool = True, pipeline_chunk_samples: int = 0,
-                 front_gate: Optional["FrontGate"] = None, fir_valu: bool = False):
+                 front_gate: Optional["FrontGate"] = None, fir_valu: bool = False,
+                 scan_tables: bool = False):
         cfg = RxConfig()
         cfg.hip_device = hip_device
         cfg.flags = ((RX_EXACT_FIR if exact_fir else 0) | (RX_KEEP_FIR if keep_fir else 0)
                      | (RX_FSM_ROUNDS if fsm_rounds else 0) | (0 if quiet_skip else RX_NO_QUIET_SKIP)
                      | (RX_COUNT_QUIET if count_quiet else 0) | (RX_SCAN_SIMS if scan_sims else 0)
                      | (RX_FRONT_GRID if front_grid else 0) | (0 if pipeline else RX_NO_PIPELINE)
-                     | (RX_FIR_VALU if fir_valu else 0))
+                     | (RX_FIR_VALU if fir_valu else 0) | (RX_SCAN_TABLES if scan_tables else 0))
         cfg.threshold = threshold
         cfg.samples_per_buffer = samples_per_buffer
         cfg.max_samples = max_samples

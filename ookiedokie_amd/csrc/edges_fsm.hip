@@ -629,6 +629,7 @@ __device__ __forceinline__ uint32_t bit_at(const uint64_t *words, uint64_t i) {
 // incoming state.  The choice only affects how many fix-point rounds are
 // needed, never the result.
 __global__ __launch_bounds__(64) void fsm_cuts_kernel(const FsmParams p) {
+    if (p.edge_overflow && *p.edge_overflow) return;        // blk_offset counts edges that were never written
     const uint32_t id = blockIdx.x;                 // capture * (segs+1) + boundary
     const uint32_t per = p.segs_per_cap + 1;
     const uint32_t cap = id / per, bi = id % per;
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(64) void fsm_cuts_kernel(const FsmParams p) {
 
 __global__ __launch_bounds__(64) void fsm_prepare_kernel(const FsmParams p, const FsmStateDev first,
                                                          int have_first) {
+    if (p.edge_overflow && *p.edge_overflow) return;
     const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nseg = p.num_captures * p.segs_per_cap;
     if (seg >= nseg) return;
@@ -713,6 +715,7 @@ template <bool BIG>
 __global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32_t parity, uint32_t mode,
                                                        uint32_t slot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t big_lds[];
+    if (p.edge_overflow && *p.edge_overflow) return;        // blk_offset counts edges that were never written
     const uint32_t seg = blockIdx.x;
     const uint32_t nseg = p.num_captures * p.segs_per_cap;
     const uint32_t cap = seg / p.segs_per_cap;
@@ -1008,6 +1011,7 @@ __global__ __launch_bounds__(64) void fsm_round_kernel(const FsmParams p, uint32
 
 // Compacts per-segment messages into one list (single workgroup).
 __global__ __launch_bounds__(1024) void fsm_gather_kernel(const FsmParams p) {
+    if (p.edge_overflow && *p.edge_overflow) return;
     __shared__ uint32_t part[1024];
     __shared__ unsigned long long err_total;
     const uint32_t nseg = p.num_captures * p.segs_per_cap;

@@ -525,6 +525,12 @@ struct ScanParams {
     uint16_t *super_in;         // [supergroups] entry code (scan_walk_kernel)
     uint16_t *cap_end;          // [captures] state after the last regular leaf
     uint16_t *cap_first;        // [captures] state after the first span (leaf kernel -> walk kernel)
+    // entry codes from synchronising spans (scan_sync_kernel / scan_syncwalk_kernel / scan_syncpick_kernel)
+    uint32_t *sync_rec;         // [blocks][kSyncRecWords]: see kSyncRec*
+    uint32_t *sync_fail;        // device word, zero at launch: bit 1 = the walk from the synchronising spans was tried, bit 0 = it gave up
+    uint32_t sync_try;          // this launch tries that walk first; the composing kernels only run when it gave up
+    uint64_t pre_plane;         // elements between two planes of pre_codes (the walk keeps one per candidate)
+    uint32_t lt_sync_words;     // lt_merged with append_sync_codes' tables behind the rows (lt_merged_words: without)
 };
 
 namespace {
@@ -658,7 +664,7 @@ __device__ __noinline__ uint32_t stuck_step(const LTab &T, const StuckCtx &c, ui
 
 constexpr uint32_t kCapWords = (256 + kStuckDepth + 31) / 32;
 constexpr uint32_t kLtLdsWords = 768;   // span tables up to this size are searched from LDS (shipped devices: 409)
-constexpr uint32_t kMergedLdsWords = 3072;      // merged rows up to this size are read from LDS (scan_entry_kernel)
+constexpr uint32_t kMergedLdsWords = 6144;      // merged rows (+ the sync walk's tables) up to this size are read from LDS
 #define STAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 // cap: bit kStuckDepth + l = leaf l of the block (l = -kStuckDepth .. count-1) can end stuck
 __device__ void block_sims(const LTab &T, const uint64_t *edges, uint64_t first, uint32_t count, uint32_t *res,
@@ -1561,6 +1567,7 @@ __device__ __forceinline__ void wave_compose(const LTab &T, const StuckCtx &sc, 
 //  on a 1 GiB capture, where a block's own latency is all there is: not kept)
 __global__ __launch_bounds__(64) void scan_leaf_wave_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
+    if (sp.sync_try && !(*sp.sync_fail & 1u)) return;          // the entry codes are there already (scan_syncwalk_kernel)
     __shared__ LTab T;
     __shared__ uint64_t s_resume[64];
     __shared__ uint32_t s_cap[kCapWords];
@@ -1829,7 +1836,7 @@ __host__ __device__ __forceinline__ size_t groups_lds_bytes(uint32_t Dp) { retur
 
 __global__ __launch_bounds__(kGroupsThreads) void scan_groups_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
-    if (*sp.fallback) return;
+    if (*sp.fallback || (sp.sync_try && !(*sp.sync_fail & 1u))) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // [kSuperBlocks][Dp] block tables
     uint16_t *gt = stage + (size_t)kSuperBlocks * sp.Dp;            // [kSuper][Dp] the group tables
     const uint32_t D = sp.D;            // the whole domain, stuck codes included
@@ -1863,7 +1870,7 @@ __global__ __launch_bounds__(kGroupsThreads) void scan_groups_kernel(ScanParams 
 __global__ __launch_bounds__(kScanThreads) void scan_walk_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ uint32_t x;
-    if (*sp.fallback) return;
+    if (*sp.fallback || (sp.sync_try && !(*sp.sync_fail & 1u))) return;
     uint16_t *stage = reinterpret_cast<uint16_t *>(scan_smem);      // up to 128 supergroup tables at a time
     const uint32_t max_stage = 128;
     for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
@@ -1972,6 +1979,7 @@ __device__ __noinline__ uint32_t leaf_step_fly_g(const LTab &T, const StuckCtx &
 constexpr uint32_t kEntryP0Blocks = 64;
 __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
+    if (sp.sync_try && !(*sp.sync_fail & 1u)) return;          // the entry codes are there already (scan_syncwalk_kernel)
     __shared__ LTab T;
     copy_ltab(T, sp.ltab);
     __syncthreads();
@@ -2067,7 +2075,9 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
         const uint64_t *edges = sp.f.edges + e0;
-        const StuckCtx sc{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
+        // (fast form: stuck codes search the LDS copy of the span tables too -- a stuck step through the global
+        //  ones is seven dependent trips to memory that the whole wave waits for)
+        const StuckCtx sc = fast ? StuckCtx{edges, g_lt, g_lt + noff, g_lt + noff + nint} : StuckCtx{edges, sp.lt_off, sp.lt_n0, sp.lt_pk};
         uint32_t s = sp.blk_in[gb];
         uint4 *pre = reinterpret_cast<uint4 *>(sp.pre_codes + (size_t)gb * LB);
         if (fast && LB == 64) {
@@ -2160,8 +2170,495 @@ __global__ __launch_bounds__(256) void scan_entry_kernel(ScanParams sp) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// entry codes from SYNCHRONISING spans (round 3)
+// ---------------------------------------------------------------------------
+// The composing kernels above (leaf -> groups -> walk -> entry) find the state every leaf is entered in by composing
+// functions on the whole abstract domain (116 reachable codes for p3l-nexa2012) over every leaf: 223 us of the chain
+// at 16 GiB, two thirds of it the block tables.  But an OOK capture is messages with silence between them, and a
+// long span leaves very little of the state it was entered in: every state times out into reset, a skipped rest-of-
+// buffer has ended, and the edge that ends the span finds the machine idle -- or, entered in the one state where
+// that edge is an error, dropping the next buffer.  The IMAGE of such a leaf -- the codes it can end in, over every
+// code it can be entered in -- is two or three codes.  So:
+//   scan_sync_kernel      one lane per leaf (a wave = a block): the leaf's merged-rows interval (phase 2 of
+//                         scan_entry_kernel), its two skip rows (as the leaf kernel computes them), and its image:
+//                         the interval's (host: append_sync_codes) plus the two skip rows' results.  A leaf with at
+//                         most kSyncK codes in its image, and none of the T.depth leaves before it able to end stuck
+//                         (no stuck code can enter it), is a SYNC leaf; the first of a block goes into the block's
+//                         record with its candidates.
+//   scan_syncwalk_kernel  one lane per (block with a sync leaf, candidate) -- and one for the first block of every
+//                         capture, from the capture's first span, a concrete simulation --: from behind the block's
+//                         sync leaf in that candidate through the block and on, until it has stepped through the
+//                         sync leaf of a later block: which of THAT leaf's candidates it arrives at goes into the
+//                         record.  The entry codes it passes go into the candidate's plane of pre_codes.  A step
+//                         is what a step of scan_entry_kernel's phase 1 is.
+//   scan_syncpick_kernel  one workgroup per capture: the records are maps on kSyncK candidates -- composed in a
+//                         scan (a thread per run of blocks, then 1024 maps by doubling) from the first block's one
+//                         candidate: the candidate every region was really entered in, i.e. which plane holds a
+//                         leaf's entry code (scan_emit_kernel reads that plane), and the state behind the last leaf.
+// Nothing is assumed: the image covers every code the leaf can be entered in (normal codes from the tables' closure,
+// the two skip codes evaluated for the leaf itself, stuck codes excluded by the leaves before).  What can happen is
+// that there is nothing to hold on to -- kSyncMaxRun blocks without a sync leaf (dense noise: the composing scan's
+// depth is logarithmic in such a stretch, a walk's linear) -- or a walk ends in a code the image does not list (a
+// stuck code met on the way): then sync_fail is set and the composing kernels, queued behind and otherwise returning
+// at once, run as if this had not been tried.
+constexpr uint32_t kSyncK = 4;                  // candidates per sync leaf (planes of pre_codes)
+constexpr uint32_t kSyncMaxRun = 8;             // blocks a walk runs on beyond its own
+constexpr uint32_t kSyncNone = 0xffffu;
+// a block's record (32-bit words)
+constexpr uint32_t kSyncRecWords = 8;
+constexpr uint32_t kSyncRecInfo = 0;            // split | candidates << 8 | 0x8000: leaves >= split belong to the region
+                                                // that starts in this block (0: no sync leaf, nothing starts here)
+constexpr uint32_t kSyncRecSel = 1;             // split | plane of the leaves below split << 8 | plane of the others << 12
+constexpr uint32_t kSyncRecCand = 2;            // [2] the candidates, 16 bits each
+constexpr uint32_t kSyncRecMap = 4;             // [2] per candidate, 16 bits: index among the next region's candidates,
+                                                //     | 0x8000 the walk reached the end of the capture
+constexpr uint32_t kSyncRecEnd = 6;             // [2] per candidate, 16 bits: the code behind the capture's last leaf
+
+// T, the span tables and the merged rows into LDS (every thread of the workgroup; ends with a barrier)
+__device__ __forceinline__ void stage_sync_tables(const ScanParams &sp, LTab &T, uint32_t noff, uint32_t nint) {
+    copy_ltab(T, sp.ltab);
+    for (uint32_t i = threadIdx.x; i < noff; i += blockDim.x) g_lt[i] = sp.lt_off[i];
+    for (uint32_t i = threadIdx.x; i < nint; i += blockDim.x) {
+        g_lt[noff + i] = sp.lt_n0[i];
+        g_lt[noff + nint + i] = sp.lt_pk[i];
+    }
+    for (uint32_t i = threadIdx.x; i < sp.lt_sync_words; i += blockDim.x) g_mr[i] = sp.lt_merged[i];
+    __syncthreads();
+    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
+    __syncthreads();
+}
+
+// interval of the level's merged breakpoints a length falls into (g_mr)
+__device__ __forceinline__ uint32_t merged_interval(uint32_t L, uint64_t n) {
+    const uint32_t b0 = 4 + (L ? g_mr[0] : 0u);
+    uint32_t lo = 0, hi = g_mr[L];
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g_mr[b0 + mid] <= (uint32_t)n) lo = mid;
+        else hi = mid;
+    }
+    return n <= 0xfffffff0ull ? lo : kSyncNone;
+}
+
+__global__ __launch_bounds__(256) void scan_sync_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ LTab T;
+    const uint32_t noff = 2 * (2 * sp.S + 2) + 1, nint = (sp.lt_words - noff) / 2u;
+    stage_sync_tables(sp, T, noff, nint);
+    if (*sp.fallback) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(sp.sync_fail, 2u);        // bit 1: tried (bit 0: gave up)
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, depth = T.NS ? T.depth : 0u;
+    const uint32_t LB = sp.leaf_block;          // 64: a wave is a block
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nbp0 = g_mr[0], sync_off = g_mr[3];
+    for (uint32_t gb = blockIdx.x * 4u + wave; gb < total + sp.f.num_captures; gb += gridDim.x * 4u) {
+        if (gb >= total) {
+            // one extra item per capture: its first span from the concrete incoming state
+            if (lane == 0) {
+                const uint32_t cap = gb - total;
+                uint64_t e0;
+                const uint64_t ne = cap_edges(sp.f, cap, e0);
+                PSim f;
+                Acc a;
+                const bool alive = first_leaf(T, sp, sp.f.edges + e0, ne, f, a);
+                sp.cap_first[cap] = (uint16_t)encode_post(T, f, a, alive);
+            }
+            continue;
+        }
+        uint32_t cap, lb;
+        locate_block(sp, gb, cap, lb);
+        uint64_t e0;
+        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        const uint64_t *edges = sp.f.edges + e0;
+        const uint64_t first = 1 + (uint64_t)lb * LB;
+        const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
+        bool few = false, stuckable = false;
+        uint32_t cand[kSyncK] = {kSyncNone, kSyncNone, kSyncNone, kSyncNone}, nc = 0;
+        if (lane < count) {
+            const uint64_t i = first + lane;
+            const Span span = span_of(T, edges, i);
+            const uint32_t z = merged_interval(span.L, span.n);
+            sp.rowz[(size_t)gb * LB + lane] = (uint16_t)z;
+            // the two skip rows (scan_leaf_wave_kernel's): skipping ends at `rs`; from there the machine starts in
+            // reset -- the normal row (reset, few bits) of a shorter span when the level before the skip equals
+            // the span's, a special row otherwise
+            const uint64_t rs = next_buffer_start(T, span.pos0 - 1);
+            const uint64_t end_const = span.pos0 + span.n, last = end_const + 1;
+            uint32_t skip_out[2];
+            for (uint32_t kk = 0; kk < 2; ++kk) {
+                uint32_t out;
+                if (rs >= last) {
+                    out = SNB + kk;                                 // still skipping when the span ends
+                } else {
+                    const uint64_t n2 = rs >= end_const ? 0 : end_const - rs;
+                    uint32_t pk = 0;
+                    if (n2 <= 0xfffffff0ull) pk = lt_lookup_g(noff, nint, kk == span.L ? 0u : 2 * S + kk, span.L, (uint32_t)n2);
+                    if (pk & kPkAbsolute) {
+                        out = pk & 0xffffu;
+                    } else if (pk & kPkRelative) {
+                        const uint32_t nbo = (pk >> 8) & 0xffffu;       // from a bit count of 0
+                        out = (pk & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                    } else {
+                        PSim f;                                         // position dependent or sensitive
+                        Acc a;
+                        const bool alive = run_leaf(T, SNB + kk, span, rs, f, a);
+                        out = encode_post(T, f, a, alive);
+                    }
+                }
+                skip_out[kk] = out;
+            }
+            sp.skipc[(size_t)gb * LB + lane] = skip_out[0] | (skip_out[1] << 16);
+            // the image: the interval's codes and the two skip results
+            if (z != kSyncNone && sync_off) {
+                const uint32_t w0 = g_mr[sync_off + 2u * ((span.L ? nbp0 : 0u) + z)];
+                const uint32_t w1 = g_mr[sync_off + 2u * ((span.L ? nbp0 : 0u) + z) + 1u];
+                const uint32_t n = (w1 >> 16) & 0xfu;
+                stuckable = ((w1 >> 20) & 1u) != 0;
+                if (n) {
+                    cand[0] = w0 & 0xffffu;
+                    cand[1] = w0 >> 16;
+                    cand[2] = w1 & 0xffffu;
+                    nc = n;
+                    few = true;
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 2; ++kk) {
+                        const uint32_t c = skip_out[kk];
+                        if (c == cand[0] || c == cand[1] || c == cand[2] || c == cand[3]) continue;
+                        if (nc == kSyncK || c >= SNB + 2) {
+                            few = false;
+                        } else {
+                            // (cand[nc] = c with nc in registers)
+                            cand[3] = nc == 3 ? c : cand[3];
+                            cand[2] = nc == 2 ? c : cand[2];
+                            cand[1] = nc == 1 ? c : cand[1];
+                            ++nc;
+                        }
+                    }
+                }
+            } else {
+                stuckable = depth != 0;         // (a span beyond the tables' lengths: say it can)
+            }
+        }
+        // leaves that a stuck code can enter: one of the `depth` leaves before them can end stuck -- those of the
+        // block by ballot, those in front of it looked up by the last `depth` lanes
+        uint64_t dirty = 0;
+        if (depth) {
+            const uint64_t sw = __ballot(stuckable);
+            bool pre = false;
+            if (lane >= 64u - depth) {
+                const uint64_t back = 64u - lane;           // 1 .. depth leaves in front of the block
+                if (first > back) {                         // leaf first - back >= 1
+                    const uint64_t i = first - back;
+                    const uint64_t n = edges[i] - edges[i - 1] - 1;
+                    const uint32_t L = (uint32_t)(i & 1ull) ^ T.lvl0;
+                    const uint32_t z = merged_interval(L, n);
+                    pre = z == kSyncNone || !sync_off || ((g_mr[sync_off + 2u * ((L ? nbp0 : 0u) + z) + 1u] >> 20) & 1u);
+                }
+            }
+            const uint64_t pw = __ballot(pre);
+            for (uint32_t d = 1; d <= depth; ++d) dirty |= (sw << d) | (pw >> (64u - d));
+        }
+        const uint64_t valid = __ballot(few) & ~dirty;
+        uint32_t *rec = sp.sync_rec + (size_t)gb * kSyncRecWords;
+        if (lb == 0) {
+            // the first block of a capture: its region starts at its first leaf, in the code behind the first span
+            if (lane == 0) rec[kSyncRecInfo] = 0u | (1u << 8) | 0x8000u;
+        } else if (valid == 0) {
+            if (lane == 0) rec[kSyncRecInfo] = 0u;
+        } else if (lane == (uint32_t)__builtin_ctzll(valid)) {
+            rec[kSyncRecInfo] = (lane + 1u) | (nc << 8) | 0x8000u;
+            rec[kSyncRecCand] = cand[0] | (cand[1] << 16);
+            rec[kSyncRecCand + 1] = cand[2] | (cand[3] << 16);
+        }
+    }
+}
+
+// abstract code -> the walk's (state, bit count): see scan_syncwalk_kernel
+__device__ __forceinline__ void sync_split(uint32_t code, uint32_t SNB, uint32_t NB1, uint32_t S, uint32_t rcpNB1,
+                                           uint32_t &cur, uint32_t &nb) {
+    if (code < SNB) {
+        cur = __umulhi(code, rcpNB1);
+        nb = code - __umul24(cur, NB1);
+    } else if (code < SNB + 3u) {
+        cur = S;
+        nb = code - SNB;
+    } else {
+        cur = 0x7fu;
+        nb = code;
+    }
+}
+
+// The walk.  Eight lanes per block (a "slot"; eight slots per wave), the first kSyncK of them its candidates, all
+// eight fetch for it.  A region is a run of consecutive leaves -- rowz / skipc / the planes of pre_codes are
+// [block][leaf], blocks of a capture follow each other -- from behind the block's sync leaf through the sync leaf of
+// the next block that has one (found up front: the records of the kSyncMaxRun blocks behind, one round trip).  The
+// wave goes through its slots' regions 64 leaves at a time: the slot's lanes fetch the next 64 intervals and skip
+// results of THEIR region into LDS (one round trip), then a ROLLED loop of 64 steps, every slot on its own leaves.
+// (First form: every lane over the blocks it crosses, 64 unrolled steps per block with the leaf data in registers:
+//  10 000 instructions, 158 per step with its predicates and an out-of-line call site each, and a wave paid for the
+//  union of its eight blocks' ranges -- 1 200 cycles per useful step, 114 us at 16 GiB.)
+__global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ LTab T;
+    __shared__ uint16_t s_z[4][8][64];
+    __shared__ uint32_t s_sk[4][8][64];
+    const uint32_t noff = 2 * (2 * sp.S + 2) + 1, nint = (sp.lt_words - noff) / 2u;
+    stage_sync_tables(sp, T, noff, nint);
+    if (*sp.fallback) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, slot = lane >> 3, k = lane & 7u;
+    const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, max_bits = T.max_bits, lvl0 = T.lvl0;
+    const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + NB1 - 1) / NB1);
+    const uint32_t nbp0 = g_mr[0], twoS = 2u * S;
+    const uint32_t rows2 = g_mr[3] + 2u * (g_mr[0] + g_mr[1]);     // append_sync_codes' second copy of the rows
+    uint16_t *const zq = s_z[wave][slot];
+    uint32_t *const skq = s_sk[wave][slot];
+    for (uint32_t base = (blockIdx.x * 4u + wave) * 8u; base < total; base += gridDim.x * 32u) {
+        const uint32_t gb = base + slot;
+        uint32_t *rec = sp.sync_rec + (size_t)min(gb, total - 1u) * kSyncRecWords;
+        const uint32_t info = gb < total ? rec[kSyncRecInfo] : 0u;
+        const bool region = (info & 0x8000u) != 0;              // (the same for the slot's eight lanes)
+        const bool walker = region && k < ((info >> 8) & 7u);
+        // ---- the region: leaves [f0, f0 + len) of the capture's [block][leaf] lists ------------------------
+        uint32_t cap = 0, lb = 0, gcap0 = 0, nblk = 0, len = 0, g2 = 0, info2 = 0;
+        uint64_t ne = 0;
+        const uint64_t *edges = sp.f.edges;
+        bool stop = false, bad = false;
+        if (region) {
+            locate_block(sp, gb, cap, lb);
+            uint64_t e0;
+            ne = cap_edges(sp.f, cap, e0);
+            edges = sp.f.edges + e0;
+            gcap0 = gb - lb;
+            nblk = sp.cap_block_off[cap + 1] - gcap0;
+            // the next block with a sync leaf: the records behind, all asked for at once
+            uint32_t inf[kSyncMaxRun];
+#pragma unroll
+            for (uint32_t j = 0; j < kSyncMaxRun; ++j)
+                inf[j] = lb + 1 + j < nblk ? sp.sync_rec[(size_t)(gb + 1 + j) * kSyncRecWords + kSyncRecInfo] : 0u;
+            uint32_t dist = 0;
+#pragma unroll
+            for (uint32_t j = kSyncMaxRun; j-- > 0;) {
+                if (inf[j] & 0x8000u) {
+                    dist = j + 1;
+                    info2 = inf[j];
+                }
+            }
+            const uint32_t f0 = lb * 64u + (info & 0x7fu);
+            uint32_t fend;                                      // one past the region's last leaf
+            if (dist) {
+                stop = true;
+                g2 = gb + dist;
+                fend = (lb + dist) * 64u + (info2 & 0x7fu);     // through that block's sync leaf (split - 1)
+            } else if (lb + 1 + kSyncMaxRun >= nblk) {
+                fend = (uint32_t)(ne - 1);                      // to the capture's last regular leaf (leaf i at i - 1)
+            } else {
+                bad = true;                                     // nothing to hold on to
+                fend = f0;
+            }
+            len = fend > f0 ? fend - f0 : 0u;
+        }
+        const uint32_t f0 = lb * 64u + (info & 0x7fu);
+        const size_t flat0 = (size_t)gcap0 * 64u + f0;          // where the region starts in rowz / skipc / a plane
+        uint16_t *plane = sp.pre_codes + (size_t)min(k, kSyncK - 1u) * sp.pre_plane + flat0;
+        const StuckCtx sc{edges, g_lt, g_lt + noff, g_lt + noff + nint};
+        // the walk's state: machine state / bit count; skip and poison as state S with bit count 0 / 1 / 2 (the rows
+        // are made of that: no division per step); a stuck code as state 0x7f with the code for a bit count
+        uint32_t cur = 0, nb = 0;
+        if (walker) {
+            const uint32_t s0 = lb == 0 ? (uint32_t)sp.cap_first[cap] : (rec[kSyncRecCand + (k >> 1)] >> (16u * (k & 1u))) & 0xffffu;
+            sync_split(s0, SNB, NB1, S, rcpNB1, cur, nb);
+        }
+        // ---- 64 leaves at a time -----------------------------------------------------------------------------
+        for (uint32_t c0 = 0; __ballot(c0 < len) != 0; c0 += 64) {
+            if (c0 < len) {
+                // the slot's eight lanes fetch its next 64 leaves (beyond the region's end: whatever is there --
+                // the lists are padded --, never read)
+                uint32_t zv[8], sv[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    zv[j] = sp.rowz[flat0 + c0 + 8u * k + j];
+                    sv[j] = sp.skipc[flat0 + c0 + 8u * k + j];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    zq[8u * k + j] = (uint16_t)zv[j];
+                    skq[8u * k + j] = sv[j];
+                }
+            }
+            wave_sync_lds();
+            const uint32_t left = len > c0 ? min(len - c0, 64u) : 0u;
+            // level of the chunk's first leaf (leaf i = f + 1 runs at lvl0 ^ (i & 1)); it alternates
+            for (uint32_t j = 0; __ballot(walker && j < left) != 0; ++j) {
+                if (walker && j < left) {
+                    const uint32_t lvbase = (((f0 + c0 + j + 1u) & 1u) ^ lvl0) ? nbp0 : 0u;
+                    const uint32_t z = zq[j];
+                    plane[c0 + j] = (uint16_t)(cur | (nb << 7));
+                    const bool plain = cur < S && z != kSyncNone;
+                    uint32_t q = g_mr[rows2 + __umul24(lvbase + (plain ? z : 0u), twoS) + 2u * min(cur, S - 1u) + (nb >= max_bits ? 1u : 0u)];
+                    q = plain ? q : 0u;
+                    if ((int32_t)q < 0) {
+                        // state' | bit count (absolute) or bits appended (relative) << 8
+                        nb = min(((q & 0x40000000u) ? nb : 0u) + ((q >> 8) & 0xffffu), NB1 - 1u);
+                        cur = q & 0xffu;
+                    } else {
+                        // skip codes: scan_sync_kernel's skip rows; stuck codes, rows that need a simulation: the full step
+                        uint32_t code = cur < S ? __umul24(cur, NB1) + nb : (cur == S ? SNB + nb : nb);
+                        if (cur == S && nb < 2u) {
+                            code = (skq[j] >> (16u * nb)) & 0xffffu;
+                        } else {
+                            const uint32_t f = f0 + c0 + j;             // leaf i = f + 1 of the capture
+                            code = leaf_step_fly_g(T, sc, noff, nint, (uint64_t)f + 1u, edges[f], edges[f + 1u], code);
+                        }
+                        sync_split(code, SNB, NB1, S, rcpNB1, cur, nb);
+                    }
+                }
+            }
+            wave_sync_lds();
+        }
+        const uint32_t s = cur < S ? __umul24(cur, NB1) + nb : (cur == S ? SNB + nb : nb);
+        // ---- where the walk arrived ----------------------------------------------------------------------------
+        if (walker) {
+            uint32_t arrive = 0;
+            if (stop) {
+                // which of that leaf's candidates it is
+                const uint32_t c01 = sp.sync_rec[(size_t)g2 * kSyncRecWords + kSyncRecCand];
+                const uint32_t c23 = sp.sync_rec[(size_t)g2 * kSyncRecWords + kSyncRecCand + 1];
+                const uint32_t nc2 = (info2 >> 8) & 7u;
+                const uint32_t cc[kSyncK] = {c01 & 0xffffu, c01 >> 16, c23 & 0xffffu, c23 >> 16};
+                arrive = kSyncK;
+#pragma unroll
+                for (uint32_t j = 0; j < kSyncK; ++j)
+                    if (j < nc2 && cc[j] == s && arrive == kSyncK) arrive = j;
+                if (arrive == kSyncK) {         // not in the image: a stuck code (or poison) met on the way
+                    bad = true;
+                    arrive = 0;
+                    if (sp.f.debug && atomicAdd(reinterpret_cast<unsigned long long *>(sp.f.debug + 56), 1ull) == 0) {
+                        sp.f.debug[57] = gb | ((uint64_t)k << 32);
+                        sp.f.debug[58] = s | ((uint64_t)len << 32);
+                        sp.f.debug[59] = c01 | ((uint64_t)c23 << 32);
+                        sp.f.debug[60] = info | ((uint64_t)info2 << 32);
+                        sp.f.debug[61] = g2 | ((uint64_t)f0 << 32);
+                        sp.f.debug[62] = rec[kSyncRecCand] | ((uint64_t)rec[kSyncRecCand + 1] << 32);
+                    }
+                }
+            }
+            if (bad && !stop && sp.f.debug) sp.f.debug[63] = gb | ((uint64_t)lb << 32);
+            // (16-bit stores: the candidates of a block write the halves of the same words)
+            reinterpret_cast<uint16_t *>(rec + kSyncRecMap)[k] = (uint16_t)(arrive | (stop ? 0u : 0x8000u));
+            reinterpret_cast<uint16_t *>(rec + kSyncRecEnd)[k] = (uint16_t)s;
+            if (bad) atomicOr(sp.sync_fail, 1u);
+        }
+    }
+}
+
+// maps on kSyncK candidates, 8 bits per entry
+__device__ __forceinline__ uint32_t sync_map_identity() { return 0x03020100u; }
+__device__ __forceinline__ uint32_t sync_map_apply(uint32_t m, uint32_t x) { return (m >> (8u * x)) & 0xffu; }
+// first a, then b
+__device__ __forceinline__ uint32_t sync_map_then(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t x = 0; x < kSyncK; ++x) r |= sync_map_apply(b, sync_map_apply(a, x) & 3u) << (8u * x);
+    return r;
+}
+// blocks per thread of scan_syncpick_kernel, at most: their records are fetched in ONE round trip and kept in
+// registers (1024 threads: captures up to 1.5 M edges; beyond, the composing kernels)
+constexpr uint32_t kPickPer = 24;
+
+__global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams sp) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint32_t maps[2][kScanThreads];
+    __shared__ uint32_t lastc[kScanThreads];
+    if (*sp.fallback || (*sp.sync_fail & 1u)) return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
+        const uint32_t gb0 = sp.cap_block_off[cap], nblk = sp.cap_block_off[cap + 1] - gb0;
+        const uint32_t per = (nblk + kScanThreads - 1) / kScanThreads;
+        if (per > kPickPer) {                   // (uniform: every thread leaves)
+            if (tid == 0) atomicOr(sp.sync_fail, 1u);
+            return;
+        }
+        const uint32_t b0 = min(tid * per, nblk);
+        uint32_t *const rec0 = sp.sync_rec + (size_t)(gb0 + b0) * kSyncRecWords;
+        uint32_t info[kPickPer], m01[kPickPer], m23[kPickPer];
+#pragma unroll
+        for (uint32_t j = 0; j < kPickPer; ++j) {
+            const bool in = j < per && b0 + j < nblk;
+            const uint32_t *rec = rec0 + (size_t)j * kSyncRecWords;
+            info[j] = in ? rec[kSyncRecInfo] : 0u;
+            m01[j] = in ? rec[kSyncRecMap] : 0u;
+            m23[j] = in ? rec[kSyncRecMap + 1] : 0u;
+        }
+        // this thread's run of blocks as ONE map: candidate at the first region that starts at or behind b0 ->
+        // candidate at the first region that starts behind the run (no region starts in the run: the same one)
+        uint32_t m = sync_map_identity();
+#pragma unroll
+        for (uint32_t j = 0; j < kPickPer; ++j) {
+            if (info[j] & 0x8000u)
+                m = sync_map_then(m, (m01[j] & 3u) | (((m01[j] >> 16) & 3u) << 8) | ((m23[j] & 3u) << 16) | (((m23[j] >> 16) & 3u) << 24));
+        }
+        // inclusive scan of the maps by doubling
+        uint32_t cur = 0;
+        maps[0][tid] = m;
+        __syncthreads();
+        for (uint32_t d = 1; d < (uint32_t)kScanThreads; d <<= 1) {
+            const uint32_t mine = maps[cur][tid];
+            maps[cur ^ 1u][tid] = tid >= d ? sync_map_then(maps[cur][tid - d], mine) : mine;
+            cur ^= 1u;
+            __syncthreads();
+        }
+        // the capture's first region has one candidate (index 0): what it has become in front of this thread's run
+        uint32_t c = tid ? sync_map_apply(maps[cur][tid - 1], 0u) & 3u : 0u;
+        // the run again: every region's true candidate (two bits each)
+        uint64_t chosen = 0;
+        uint32_t last = 0xffffffffu;
+#pragma unroll
+        for (uint32_t j = 0; j < kPickPer; ++j) {
+            if (info[j] & 0x8000u) {
+                chosen |= (uint64_t)c << (2u * j);
+                last = c;
+                const uint32_t me = ((c & 2u) ? m23[j] : m01[j]) >> (16u * (c & 1u));
+                if (me & 0x8000u) {             // its walk reached the end of the capture: the state behind the last leaf
+                    const uint32_t e = rec0[(size_t)j * kSyncRecWords + kSyncRecEnd + (c >> 1)];
+                    sp.cap_end[cap] = (uint16_t)((e >> (16u * (c & 1u))) & 0xffffu);
+                }
+                c = me & 3u;
+            }
+        }
+        // the plane of a block's leaves below its split is that of the region before: the last one that started
+        // in front of the run -- a few threads back at most (a region is kSyncMaxRun + 1 blocks at most)
+        lastc[tid] = last;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t t = tid; t-- > 0;) {
+            if (lastc[t] != 0xffffffffu) {
+                before = lastc[t];
+                break;
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kPickPer; ++j) {
+            if (j < per && b0 + j < nblk) {
+                uint32_t se;
+                if (info[j] & 0x8000u) {
+                    const uint32_t mine = (uint32_t)(chosen >> (2u * j)) & 3u;
+                    se = (info[j] & 0x7fu) | (before << 8) | (mine << 12);
+                    before = mine;
+                } else {
+                    se = 64u | (before << 8);   // every leaf below the split
+                }
+                rec0[(size_t)j * kSyncRecWords + kSyncRecSel] = se;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
-__global__ __launch_bounds__(kSimThreads) __attribute__((amdgpu_waves_per_eu(4))) void scan_emit_kernel(ScanParams sp) {
+__global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
     copy_ltab(T, sp.ltab);
@@ -2169,6 +2666,7 @@ __global__ __launch_bounds__(kSimThreads) __attribute__((amdgpu_waves_per_eu(4))
     if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
     __syncthreads();
     if (*sp.fallback) return;
+    const bool sync_form = sp.sync_try && !(*sp.sync_fail & 1u);
     const uint32_t LB = sp.leaf_block;
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     // work items: groups of FOUR blocks, then one "ends" item per capture (first span + tail).
@@ -2196,7 +2694,17 @@ __global__ __launch_bounds__(kSimThreads) __attribute__((amdgpu_waves_per_eu(4))
                 // through the LDS, no barrier -- every lane asks for its leaf's code and its two edges at once.
                 if (l < count) {
                     const uint64_t i = first + l;
-                    uint32_t in = sp.pre_codes[(size_t)w * LB + l];
+                    // (the walk from synchronising spans keeps a plane per candidate: scan_syncpick_kernel says which)
+                    size_t plane = 0;
+                    if (sync_form) {
+                        const uint32_t se = sp.sync_rec[(size_t)w * kSyncRecWords + kSyncRecSel];
+                        plane = (size_t)((l < (se & 0x7fu) ? se >> 8 : se >> 12) & 3u) * sp.pre_plane;
+                    }
+                    uint32_t in = sp.pre_codes[plane + (size_t)w * LB + l];
+                    if (sync_form) {            // state | bit count << 7 (scan_syncwalk_kernel)
+                        const uint32_t pc = in & 0x7fu, pn = in >> 7;
+                        in = pc < T.S ? pc * T.NB1 + pn : (pc == T.S ? T.S * T.NB1 + pn : pn);
+                    }
                     const uint64_t e_before = edges[i - 1], e_at = edges[i];
                     PSim f;
                     Acc a;
@@ -3024,6 +3532,84 @@ std::vector<uint32_t> build_merged_rows(uint32_t S, const std::vector<uint32_t> 
     return out;
 }
 
+// What a span does to the codes it can be entered in, per interval of the merged rows -- for the walk from
+// synchronising spans (scan_sync_kernel).  Two words per interval behind the rows, header word [3] = where they
+// start:  c0 | c1 << 16,  c2 | (n | stuckable << 4) << 16
+//   n (1..3): every normal code a span of that level can be entered in (reach: code | level mask << 14 -- bit 14:
+//             met at level 0, bit 15: at level 1; empty = every normal code at either level) ends in one of the n
+//             codes c0..c2 (absolute results, relative ones evaluated; a skip code where the entry runs into an
+//             error on the span's last sample);  n = 0: more than three, or a row that is stuck / bit-count
+//             sensitive / position dependent;
+//   stuckable: some such entry finds no trigger on the edge (the leaf can end in a stuck code).
+void append_sync_codes(std::vector<uint32_t> &merged, uint32_t S, uint32_t NB1, uint32_t max_bits,
+                       const std::vector<uint16_t> &reach) {
+    if (merged.size() < 4) return;
+    const uint32_t nbp[2] = {merged[0], merged[1]}, twoS = 2 * S, SNB = S * NB1;
+    const uint32_t rows0 = 4 + nbp[0] + nbp[1];
+    std::vector<uint16_t> codes[2];
+    for (uint32_t L = 0; L < 2; ++L) {
+        if (reach.empty()) {
+            for (uint32_t c = 0; c < SNB; ++c) codes[L].push_back((uint16_t)c);
+        } else {
+            for (uint16_t v : reach)
+                if ((v & 0x3fffu) < SNB && (v & (0x4000u << L))) codes[L].push_back((uint16_t)(v & 0x3fffu));
+        }
+    }
+    std::vector<uint32_t> out;
+    for (uint32_t L = 0; L < 2; ++L) {
+        for (uint32_t z = 0; z < nbp[L]; ++z) {
+            const uint32_t *row = merged.data() + rows0 + (size_t)((L ? nbp[0] : 0u) + z) * twoS;
+            uint32_t img[3] = {0xffffu, 0xffffu, 0xffffu}, n = 0, stuckable = 0;
+            bool ok = !codes[L].empty();
+            for (uint16_t c : codes[L]) {
+                const uint32_t cur = c / NB1, nb = c - cur * NB1;
+                const uint32_t p = row[2 * cur + (nb >= max_bits ? 1u : 0u)];
+                uint32_t end;
+                if (p & kPkAbsolute) {
+                    end = p & 0xffffu;
+                    if (end >= SNB + 2) ok = false;         // poison: not an exit the walk carries
+                } else if (p & kPkRelative) {
+                    const uint32_t nbo = nb + ((p >> 8) & 0xffffu);
+                    end = (p & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                } else {
+                    if (p & kPkStuck) stuckable = 1;
+                    ok = false;                             // stuck, bit-count sensitive, position dependent
+                    continue;
+                }
+                uint32_t j = 0;
+                while (j < n && img[j] != end) ++j;
+                if (j == n) {
+                    if (n == 3) ok = false;
+                    else img[n++] = end;
+                }
+            }
+            if (!ok) n = 0;
+            out.push_back(img[0] | (img[1] << 16));
+            out.push_back(img[2] | ((n | (stuckable << 4)) << 16));
+        }
+    }
+    // ... and the rows once more in the form the walk steps through (a state is kept as state / bit count, skip and
+    // poison as state S with bit count 0 / 1 / 2): state' | (bit count or bits appended) << 8 | relative << 30 |
+    // 0x80000000; 0 = not a plain result (stuck, bit-count sensitive, position dependent): the full step
+    std::vector<uint32_t> rows2;
+    for (size_t i = rows0; i < merged.size(); ++i) {
+        const uint32_t p = merged[i];
+        uint32_t q = 0;
+        if (p & kPkAbsolute) {
+            const uint32_t code = p & 0xffffu;
+            const uint32_t cur = code < SNB ? code / NB1 : S, nb = code < SNB ? code - cur * NB1 : code - SNB;
+            if (code < SNB + 3) q = cur | (nb << 8) | 0x80000000u;
+        } else if (p & kPkRelative) {
+            const uint32_t add = (p >> 8) & 0xffffu;
+            q = (p & 0xffu) | ((add > NB1 ? NB1 : add) << 8) | 0x40000000u | 0x80000000u;
+        }
+        rows2.push_back(q);
+    }
+    merged[3] = (uint32_t)merged.size();
+    merged.insert(merged.end(), out.begin(), out.end());
+    merged.insert(merged.end(), rows2.begin(), rows2.end());
+}
+
 uint32_t fsm_scan_fin_block() { return (uint32_t)kFinBlock; }
 
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end) {
@@ -3076,6 +3662,11 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.cap_super_off = a.cap_super_off;
     sp.super_tab = a.super_tab;
     sp.super_in = a.super_in;
+    sp.sync_rec = a.sync_rec;
+    sp.sync_fail = a.sync_fail;
+    sp.sync_try = 0;
+    sp.pre_plane = a.pre_plane;
+    sp.lt_sync_words = a.lt_sync_words;
     sp.cap_end = a.cap_end;
     sp.cap_first = a.cap_first;
     const size_t lds = block_lds_bytes(a.leaf_block, a.D, a.S, a.SNB);
@@ -3147,10 +3738,20 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     static const char *const grid_env = dev_getenv("OOKD_SCAN_GRID");
     const uint32_t leaf_blocks = grid_env ? (uint32_t)atoi(grid_env) : leaf_grid;
     const uint32_t emit_blocks = grid_env ? (uint32_t)atoi(grid_env) : emit_grid;
-    hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
-    // (before the leaf kernel's launch: it is the one that fills the list)
     sp.skipc = wave_form ? a.skipc : nullptr;
     sp.skipc_valid = sp.skipc ? 1u : 0u;
+    sp.pre_codes = a.pre_codes;
+    sp.blk_in = a.blk_in;
+    sp.rowz = a.rowz;
+    // entry codes from synchronising spans first; the composing kernels behind them return at once unless that gave up
+    sp.sync_try = (a.sync_try && wave_form && a.lt_merged && a.lt_sync_words && a.lt_sync_words <= kMergedLdsWords && a.rowz && a.skipc &&
+                   a.pre_codes && a.pre_plane && a.sync_rec && a.sync_fail) ? 1u : 0u;
+    hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
+    if (sp.sync_try) {
+        hipLaunchKernelGGL(scan_sync_kernel, dim3(512), dim3(256), 0, stream, sp);
+        hipLaunchKernelGGL(scan_syncwalk_kernel, dim3(512), dim3(256), 0, stream, sp);
+        hipLaunchKernelGGL(scan_syncpick_kernel, dim3(cap_grid), dim3(kScanThreads), 0, stream, sp);
+    }
     if (wave_form) {
         hipLaunchKernelGGL(scan_leaf_wave_kernel, dim3(grid_env ? (uint32_t)atoi(grid_env) : wave_grid), dim3(64), lds_wave, stream, sp);
     } else {

@@ -278,6 +278,9 @@ struct FsmParams {
     uint32_t stamp_bits;
     const uint32_t *big;        // tables of a device with more than 64 states / triggers (see kMaxStatesBig), or null
     uint32_t big_words;
+    // the edge stage's overflow flag (device): set = the list's tail was never written and blk_offset counts
+    // edges that are not there -- the round-form kernels return at once (the host reports OOKD_ERR_CAPACITY)
+    const uint32_t *edge_overflow;
 };
 
 // level of decimated sample `pos` of capture `cap` (pos may be -1 for a chunk: the sample in front of it)
@@ -377,6 +380,11 @@ struct FsmScanArgs {
     uint16_t *super_in;         // same count
     uint16_t *cap_end;          // [captures]
     uint16_t *cap_first;        // [captures]
+    uint32_t *sync_rec;         // [total_blocks_cap][8] the walk's block records (fsm_scan.hip, kSyncRec*)
+    uint64_t pre_plane;         // pre_codes holds 4 planes this many elements apart (0: one plane, no such walk)
+    uint32_t lt_sync_words;     // lt_merged's size with append_sync_codes' tables (lt_merged_words: the rows alone)
+    uint32_t *sync_fail;        // device word, zero at launch: the walk from the synchronising spans gave up
+    uint32_t sync_try;          // try that walk first (needs the merged rows with append_sync_codes' words)
 };
 
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB);
@@ -401,6 +409,11 @@ bool build_leaf_tables(const FsmTablesDev &tables, uint32_t spb, uint32_t decim,
 //   rows level 1 [nbp1][2S]
 std::vector<uint32_t> build_merged_rows(uint32_t S, const std::vector<uint32_t> &off, const std::vector<uint32_t> &n0,
                                         const std::vector<uint32_t> &pk);
+// Marks the intervals of the merged rows in which a span is SYNCHRONISING (every row a span of that level can be
+// entered in holds the same absolute normal code): one word per interval behind the rows (the code, or 0xffff),
+// header word [3] = where they start.  reach: code | level mask << 14 as build_leaf_tables returns it.
+void append_sync_codes(std::vector<uint32_t> &merged, uint32_t S, uint32_t NB1, uint32_t max_bits,
+                       const std::vector<uint16_t> &reach);
 uint32_t fsm_scan_fin_block();
 // t_end (optional): event that takes the end time stamp of the scan's last kernel
 hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t t_end = nullptr);

@@ -46,7 +46,7 @@ struct ResultHeader {
     unsigned long long recompute;
     uint32_t total_edges;
     uint32_t scan_fallback;
-    uint32_t reserved0;
+    uint32_t sync_fail;         // the scan's walk from synchronising spans gave up (the composing kernels ran)
     uint32_t publish_done;      // workgroups of the scan's publishing kernel that are through
 };
 
@@ -369,6 +369,10 @@ struct ookd_rx {
     DevBuf<uint16_t> d_pre, d_blk_in;       // entry code of every leaf / block (scan_entry_kernel)
     DevBuf<uint16_t> d_rowz;                // merged-rows interval of every leaf (scan_entry_kernel)
     DevBuf<uint32_t> d_skipc;               // every leaf applied to the two skip codes (leaf kernel -> entry walk)
+    DevBuf<uint32_t> d_sync_rec;            // the block records of the walk from synchronising spans
+    uint64_t pre_plane = 0;                 // elements per plane of d_pre (4 planes when that walk can run)
+    uint32_t lt_merged_rows = 0;            // size of d_lt_merged without append_sync_codes' tables
+    bool scan_sync = false;                 // try the walk from synchronising spans first
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
@@ -472,6 +476,7 @@ struct ookd_rx {
         d_blk_in.release();
         d_rowz.release();
         d_skipc.release();
+        d_sync_rec.release();
         d_chunk_totals.release();
         d_fin_tickets.release();
         for (auto &e : ev_c0) if (e) (void)hipEventDestroy(e);
@@ -629,6 +634,7 @@ struct ookd_rx {
         f.msg_capacity = msg_capacity;
         f.totals = d_hdr.p->totals;
         f.debug = d_debug.p;
+        f.edge_overflow = &d_hdr.p->edge_overflow;
         const uint32_t tile_bits = front_tile_bits(front_params(nullptr, 0));
         if (tile_bits && d_tile_info.p) {
             f.tile_info = d_tile_info.p;
@@ -782,6 +788,7 @@ int ookd_rx::run_pipelined(const void *d_iq) {
     scan_used = false;
     scan_pending = true;
     stats.fsm_path = 0;
+    stats.scan_entry_form = 0;
     stats.fsm_fallback_reason = 0;
     pending_first_valid = false;
     // every front-end launch first: the device starts on the capture at once and is not held up by
@@ -837,7 +844,8 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.lt_pk = d_lt_pk.p;
         a.lt_words = (uint32_t)(d_lt_off.n + d_lt_n0.n + d_lt_pk.n);
         a.lt_merged = d_lt_merged.p;
-        a.lt_merged_words = (uint32_t)d_lt_merged.n;
+        a.lt_merged_words = lt_merged_rows;
+        a.lt_sync_words = (uint32_t)d_lt_merged.n;
         a.ltab = d_ltab.p;
         a.reach = d_reach.p;
         a.nreach = scan_reach_n;
@@ -878,6 +886,14 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.blk_in = d_blk_in.p;
         a.rowz = d_rowz.p;
         a.skipc = d_skipc.p;
+    a.sync_rec = d_sync_rec.p;
+    a.pre_plane = pre_plane;
+    a.sync_fail = &d_hdr.p->sync_fail;
+    a.sync_try = scan_sync ? 1u : 0u;
+        a.sync_rec = d_sync_rec.p;
+        a.pre_plane = pre_plane;
+        a.sync_fail = &d_hdr.p->sync_fail;
+        a.sync_try = scan_sync ? 1u : 0u;
         a.final_state = d_carry.p + (c & 1);
         a.fallback = &d_hdr.p->scan_fallback;
         a.fin_off = d_fin_off.p;
@@ -1117,6 +1133,7 @@ int ookd_rx::run_state_machine(const FsmStateDev *first, bool fresh) {
     scan_used = false;
     scan_pending = false;
     stats.fsm_path = 0;
+    stats.scan_entry_form = 0;
     stats.fsm_fallback_reason = 0;
     if (!have_fsm || run_n_out == 0) {
         HIPCHK(hipEventRecord(ev[2], stream));
@@ -1154,7 +1171,8 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.lt_pk = d_lt_pk.p;
     a.lt_words = (uint32_t)(d_lt_off.n + d_lt_n0.n + d_lt_pk.n);
     a.lt_merged = d_lt_merged.p;
-    a.lt_merged_words = (uint32_t)d_lt_merged.n;
+    a.lt_merged_words = lt_merged_rows;
+    a.lt_sync_words = (uint32_t)d_lt_merged.n;
     a.ltab = d_ltab.p;
     a.reach = d_reach.p;
     a.nreach = scan_reach_n;
@@ -1188,6 +1206,10 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.blk_in = d_blk_in.p;
     a.rowz = d_rowz.p;
     a.skipc = d_skipc.p;
+    a.sync_rec = d_sync_rec.p;
+    a.pre_plane = pre_plane;
+    a.sync_fail = &d_hdr.p->sync_fail;
+    a.sync_try = scan_sync ? 1u : 0u;
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = d_fin_tickets.p + kMaxChunks;
@@ -1211,6 +1233,14 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
                     (unsigned long long)(c[1] - c[0]), (unsigned long long)(c[2] - c[1]), (unsigned long long)(c[3] - c[2]),
                     (unsigned long long)(c[4] - c[3]), (unsigned long long)(c[5] - c[4]));
         }
+        uint64_t dbg2[8];
+        HIPCHK(hipMemcpy(dbg2, d_debug.p + 56, sizeof(dbg2), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(d_debug.p + 56, 0, sizeof(dbg2)));
+        fprintf(stderr, "[scan] sync walk: %llu arrivals outside the image; first: block %u cand %u code %u len %u, image %08x %08x, info %08x next %08x, "
+                        "next block %u f0 %u, own cands %08x %08x; nothing to hold on to at block %u (%u)\n",
+                (unsigned long long)dbg2[0], (uint32_t)dbg2[1], (uint32_t)(dbg2[1] >> 32), (uint32_t)dbg2[2], (uint32_t)(dbg2[2] >> 32),
+                (uint32_t)dbg2[3], (uint32_t)(dbg2[3] >> 32), (uint32_t)dbg2[4], (uint32_t)(dbg2[4] >> 32), (uint32_t)dbg2[5],
+                (uint32_t)(dbg2[5] >> 32), (uint32_t)dbg2[6], (uint32_t)(dbg2[6] >> 32), (uint32_t)dbg2[7], (uint32_t)(dbg2[7] >> 32));
         for (int i = 0; i < 4; ++i)
             fprintf(stderr, "[scan] leaf block %d: sims %llu expand %llu compose %llu ticks, %llu unique spans, cap %llx\n", i,
                     (unsigned long long)dbg[4 * i], (unsigned long long)dbg[4 * i + 1],
@@ -1282,7 +1312,12 @@ int ookd_rx::collect_results() {
         if (h_hdr->scan_fallback == 0) {
             scan_used = true;
             stats.fsm_path = 1;
+            stats.scan_entry_form = (h_hdr->sync_fail & 3u) == 2u ? 1u : 2u;
             redo_some = run_caps > 1 && (h_hdr->flags & 2u) != 0;
+        } else if (h_hdr->edge_overflow) {
+            // refused because the edge list overflowed: there is nothing to run the rounds on (blk_offset counts
+            // edges that were never written); reported below
+            stats.fsm_fallback_reason = h_hdr->scan_fallback;
         } else if (!chunks.empty()) {
             // the scan refused a chunk of a pipelined run: the whole capture again, unchunked (the
             // last chunk's publishing kernel left the device header zeroed)
@@ -1312,6 +1347,7 @@ int ookd_rx::collect_results() {
             ResultHeader keep = *h_hdr;
             keep.totals[0] = keep.totals[1] = 0;
             keep.scan_fallback = 0;
+            keep.sync_fail = 0;
             HIPCHK(hipMemcpyAsync(d_hdr.p, &keep, sizeof(keep), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));
             hdr_dirty = true;
@@ -1644,7 +1680,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
         rc |= rx->d_seg_msg_count.alloc(nseg);
         rc |= rx->d_seg_err_count.alloc(nseg);
         rc |= rx->d_seg_errs.alloc(nseg * rx->err_slots);
-        if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4 + 64);
+        if (getenv("OOKD_DEBUG")) rc |= rx->d_debug.alloc(nseg * 4 + 128);
         // scan form: abstract states = states x bit counts + skip x2 + poison
         rx->scan_S = (uint32_t)device->state_duration_us.size();
         rx->scan_max_bits = device->num_bits;
@@ -1711,7 +1747,14 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                      hipMemcpy(rx->d_lt_pk.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice) != hipSuccess)) {
                     rc = OOKD_ERR_HIP;
                 }
-                const std::vector<uint32_t> merged = build_merged_rows(rx->scan_S, off, n0, pk);
+                std::vector<uint32_t> merged = build_merged_rows(rx->scan_S, off, n0, pk);
+                rx->lt_merged_rows = (uint32_t)merged.size();
+                {
+                    // (reach: the level lists were appended behind the scan_reach_n masked codes above)
+                    const std::vector<uint16_t> masked(reach.begin(), reach.begin() + (reach.empty() ? 0 : rx->scan_reach_n));
+                    append_sync_codes(merged, rx->scan_S, device->num_bits + 2, device->num_bits, masked);
+                    rx->scan_sync = !(cfg->flags & OOKD_RX_SCAN_TABLES) && !dev_getenv("OOKD_SCAN_NO_SYNC");
+                }
                 rc |= rx->d_lt_merged.alloc(merged.size());
                 if (rc == OOKD_OK && hipMemcpy(rx->d_lt_merged.p, merged.data(), merged.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
                     rc = OOKD_ERR_HIP;
@@ -1745,9 +1788,12 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
-            rc |= rx->d_pre.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
+            // (the walk from synchronising spans keeps a plane of entry codes per candidate)
+            rx->pre_plane = rx->scan_sync ? (size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64 : 0;
+            rc |= rx->d_pre.alloc(((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64) * (rx->scan_sync ? 4 : 1));
             rc |= rx->d_rowz.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_skipc.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
+            rc |= rx->d_sync_rec.alloc(((size_t)rx->scan_blocks_cap + 8) * 8);
             rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);
@@ -2009,6 +2055,49 @@ int ookd_scan_domain_info(const ookd_device *device, uint32_t samples_per_buffer
             }
         }
     }
+    // ... and the sync walk's second copy of the rows (append_sync_codes) must step every normal code exactly as the
+    // rows do, and every interval's image must hold what its reachable codes end in
+    if (ok && merged_ok && !n0.empty()) {
+        std::vector<uint32_t> m = build_merged_rows(S, off, n0, pk);
+        const uint32_t NB1 = device->num_bits + 2, max_bits = device->num_bits, SNB = S * NB1;
+        append_sync_codes(m, S, NB1, max_bits, reach);
+        const uint32_t nbp[2] = {m[0], m[1]}, rows0 = 4 + m[0] + m[1], sync_off = m[3];
+        const uint32_t rows2 = sync_off + 2 * (nbp[0] + nbp[1]);
+        if (m.size() != rows2 + (size_t)(nbp[0] + nbp[1]) * 2 * S) merged_ok = false;
+        for (uint32_t L = 0; L < 2 && merged_ok; ++L) {
+            for (uint32_t z = 0; z < nbp[L] && merged_ok; ++z) {
+                const size_t at = (size_t)((L ? nbp[0] : 0u) + z) * 2 * S;
+                const uint32_t w0 = m[sync_off + 2 * ((L ? nbp[0] : 0u) + z)], w1 = m[sync_off + 2 * ((L ? nbp[0] : 0u) + z) + 1];
+                const uint32_t nimg = (w1 >> 16) & 0xfu, img[3] = {w0 & 0xffffu, w0 >> 16, w1 & 0xffffu};
+                for (uint32_t c = 0; c < SNB && merged_ok; ++c) {
+                    const uint32_t cur = c / NB1, nb = c - cur * NB1, r = 2 * cur + (nb >= max_bits ? 1u : 0u);
+                    const uint32_t pp = m[rows0 + at + r], q = m[rows2 + at + r];
+                    uint32_t want = 0xffffffffu;
+                    if (pp & 0x80000000u) {
+                        want = pp & 0xffffu;
+                    } else if (pp & 0x20000000u) {
+                        const uint32_t nbo = nb + ((pp >> 8) & 0xffffu);
+                        want = (pp & 0xffu) * NB1 + (nbo >= NB1 ? NB1 - 1 : nbo);
+                    }
+                    if (want == 0xffffffffu || want >= SNB + 3) {
+                        if (q != 0) merged_ok = false;
+                        continue;
+                    }
+                    if (!(q & 0x80000000u)) {
+                        merged_ok = false;
+                        continue;
+                    }
+                    const uint32_t nb2 = std::min(((q & 0x40000000u) ? nb : 0u) + ((q >> 8) & 0xffffu), NB1 - 1u), cur2 = q & 0xffu;
+                    const uint32_t got = cur2 < S ? cur2 * NB1 + nb2 : SNB + nb2;
+                    if (got != want) merged_ok = false;
+                    // a reachable code's result is in the image (when the interval has one)
+                    bool reachable = reach.empty();
+                    for (uint16_t v : reach) reachable = reachable || ((v & 0x3fffu) == c && (v & (0x4000u << L)));
+                    if (nimg && reachable && want != img[0] && want != img[1] && want != img[2]) merged_ok = false;
+                }
+            }
+        }
+    }
     out[0] = (ok && merged_ok) ? 1u : 0u;
     out[1] = (uint32_t)n0.size();
     out[2] = (uint32_t)zeros;
@@ -2094,7 +2183,7 @@ int ookd_rx_shard_refine(ookd_rx *rx, const ookd_fsm_state *state_in, ookd_fsm_s
     if (rx->scan_used) {
         // the scan is cheap enough to simply run again from the new incoming state
         HIPCHK(hipMemsetAsync(rx->d_hdr.p->totals, 0, sizeof(uint64_t) * 2, rx->stream));
-        HIPCHK(hipMemsetAsync(&rx->d_hdr.p->scan_fallback, 0, sizeof(uint32_t), rx->stream));
+        HIPCHK(hipMemsetAsync(&rx->d_hdr.p->scan_fallback, 0, 2 * sizeof(uint32_t), rx->stream));   // + sync_fail
         rc = rx->run_state_machine(reinterpret_cast<const FsmStateDev *>(state_in), true);
     } else {
         rc = rx->fsm_to_fixpoint(reinterpret_cast<const FsmStateDev *>(state_in), false, true);

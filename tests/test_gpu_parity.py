@@ -65,15 +65,19 @@ def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, chec
     # state machine forms: scan with span tables, scan simulating every span, rounds; then the scan
     # again with the capture pipelined in small chunks (front end of chunk c+1 beside the state
     # machine of chunk c, state carried on the device) and with the packed-VALU form of the 1-stage
-    # front end instead of the matrix-core one (the default wherever it applies)
-    for fsm_rounds, scan_sims, chunk, valu in ((False, False, 0, False), (False, True, 0, False), (True, False, 0, False),
-                                               (False, False, 4 * spb, False), (False, False, 0, True)):
+    # front end instead of the matrix-core one (the default wherever it applies); and the scan with its entry
+    # states from composed block tables only (the default first tries the walk from synchronising spans)
+    for fsm_rounds, scan_sims, chunk, valu, tables in (
+            (False, False, 0, False, False), (False, True, 0, False, False), (True, False, 0, False, False),
+            (False, False, 4 * spb, False, False), (False, False, 0, True, False), (False, False, 0, False, True)):
         rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
                          exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
                          fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims,
-                         pipeline_chunk_samples=chunk, fir_valu=valu)
+                         pipeline_chunk_samples=chunk, fir_valu=valu, scan_tables=tables)
         got = rx.rx(iq)
         assert got.stats["decimated_samples"] == want.decimated
+        if tables and got.stats["fsm_path"] == 1:
+            assert got.stats["scan_entry_form"] == 2
         if chunk and expect_scan and spb % 4096 == 0 and n >= 16 * spb and got.stats["fsm_fallback_reason"] == 0:
             assert got.stats["pipeline_chunks"] >= 2, "the capture was not pipelined"
         assert got.stats["num_edges"] == len(edges_of(want.bits))
