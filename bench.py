@@ -212,6 +212,9 @@ def main():
             return "fir1_mfma_kernel (unpack + split-fp16 Toeplitz FIR on the matrix cores + threshold + bitpack)"
         if filt.num_stages == 1:
             return "fir1_bits_kernel (unpack+FIR+threshold+bitpack)"
+        if filt.num_stages == 2 and filt.total_decimation == 4 and not exact and not os.environ.get("OOKD_FIR_VALU"):
+            return ("fir2_mfma_kernel (unpack + the two decimate-by-2 stages folded into one decimate-by-4 Toeplitz FIR on "
+                    "the matrix cores + threshold + bitpack)")
         if filt.num_stages == 2:
             return "fir2_bits_kernel (unpack + two decimating FIR stages + threshold + bitpack)"
         return "fir_generic_kernel"

@@ -68,7 +68,7 @@ constexpr uint32_t kMaxStuck = 256;     // normal codes that can get stuck (p3l-
 constexpr uint32_t kMaxStuckRows = 32;
 
 // reasons in the fallback word
-enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8 };
+enum { kFbPoison = 1, kFbOverflow = 2, kFbBlocks = 4, kFbPool = 8, kFbSync = kScanFbSync };
 
 // Tables in LDS, one 16-byte record per state / trigger: a simulation step is
 // a chain of dependent table reads (~100 cycles each), so what belongs
@@ -527,8 +527,11 @@ struct ScanParams {
     uint16_t *cap_first;        // [captures] state after the first span (leaf kernel -> walk kernel)
     // entry codes from synchronising spans (scan_sync_kernel / scan_syncwalk_kernel / scan_syncpick_kernel)
     uint32_t *sync_rec;         // [blocks][kSyncRecWords]: see kSyncRec*
+    uint32_t *sync_dig;         // [blocks] what scan_syncpick_kernel needs of a record, in one word (kSyncDig*)
+    uint32_t *sync_sel;         // [blocks] split | plane of the leaves below it << 8 | plane of the others << 12
     uint32_t *sync_fail;        // device word, zero at launch: bit 1 = the walk from the synchronising spans was tried, bit 0 = it gave up
     uint32_t sync_try;          // this launch tries that walk first; the composing kernels only run when it gave up
+    uint32_t sync_only;         // ... and are not even queued: giving up refuses the run (kFbSync), the host composes
     uint64_t pre_plane;         // elements between two planes of pre_codes (the walk keeps one per candidate)
     uint32_t lt_sync_words;     // lt_merged with append_sync_codes' tables behind the rows (lt_merged_words: without)
 };
@@ -2209,11 +2212,13 @@ constexpr uint32_t kSyncNone = 0xffffu;
 constexpr uint32_t kSyncRecWords = 8;
 constexpr uint32_t kSyncRecInfo = 0;            // split | candidates << 8 | 0x8000: leaves >= split belong to the region
                                                 // that starts in this block (0: no sync leaf, nothing starts here)
-constexpr uint32_t kSyncRecSel = 1;             // split | plane of the leaves below split << 8 | plane of the others << 12
 constexpr uint32_t kSyncRecCand = 2;            // [2] the candidates, 16 bits each
-constexpr uint32_t kSyncRecMap = 4;             // [2] per candidate, 16 bits: index among the next region's candidates,
-                                                //     | 0x8000 the walk reached the end of the capture
+                                                // (words 1, 4, 5: spare)
 constexpr uint32_t kSyncRecEnd = 6;             // [2] per candidate, 16 bits: the code behind the capture's last leaf
+
+// a record's digest: split | 0x80 a region starts here | candidates << 8 | per candidate 3 bits from bit 11: index among
+// the next region's candidates, | 4: its walk reached the end of the capture
+constexpr uint32_t kSyncDigMap = 11;
 
 // T, the span tables and the merged rows into LDS (every thread of the workgroup; ends with a barrier)
 __device__ __forceinline__ void stage_sync_tables(const ScanParams &sp, LTab &T, uint32_t noff, uint32_t nint) {
@@ -2280,7 +2285,9 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(ScanParams sp) {
             const uint64_t i = first + lane;
             const Span span = span_of(T, edges, i);
             const uint32_t z = merged_interval(span.L, span.n);
-            sp.rowz[(size_t)gb * LB + lane] = (uint16_t)z;
+            // (for the walk: where the leaf's row set starts in the rows, in words -- not the interval, which is what
+            //  scan_entry_kernel's phase 2 leaves in the same list when the composing kernels run)
+            sp.rowz[(size_t)gb * LB + lane] = z != kSyncNone ? (uint16_t)(((span.L ? nbp0 : 0u) + z) * 2u * S) : (uint16_t)kSyncNone;
             // the two skip rows (scan_leaf_wave_kernel's): skipping ends at `rs`; from there the machine starts in
             // reset -- the normal row (reset, few bits) of a shorter span when the level before the skip equals
             // the span's, a special row otherwise
@@ -2366,7 +2373,10 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(ScanParams sp) {
             // the first block of a capture: its region starts at its first leaf, in the code behind the first span
             if (lane == 0) rec[kSyncRecInfo] = 0u | (1u << 8) | 0x8000u;
         } else if (valid == 0) {
-            if (lane == 0) rec[kSyncRecInfo] = 0u;
+            if (lane == 0) {
+                rec[kSyncRecInfo] = 0u;
+                sp.sync_dig[gb] = 0u;           // (a block where a region starts gets its digest from the walk)
+            }
         } else if (lane == (uint32_t)__builtin_ctzll(valid)) {
             rec[kSyncRecInfo] = (lane + 1u) | (nc << 8) | 0x8000u;
             rec[kSyncRecCand] = cand[0] | (cand[1] << 16);
@@ -2409,9 +2419,8 @@ __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
     if (*sp.fallback) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, slot = lane >> 3, k = lane & 7u;
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
-    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, max_bits = T.max_bits, lvl0 = T.lvl0;
+    const uint32_t S = T.S, NB1 = T.NB1, SNB = S * NB1, max_bits = T.max_bits;
     const uint32_t rcpNB1 = (uint32_t)((0x100000000ull + NB1 - 1) / NB1);
-    const uint32_t nbp0 = g_mr[0], twoS = 2u * S;
     const uint32_t rows2 = g_mr[3] + 2u * (g_mr[0] + g_mr[1]);     // append_sync_codes' second copy of the rows
     uint16_t *const zq = s_z[wave][slot];
     uint32_t *const skq = s_sk[wave][slot];
@@ -2490,14 +2499,12 @@ __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
             }
             wave_sync_lds();
             const uint32_t left = len > c0 ? min(len - c0, 64u) : 0u;
-            // level of the chunk's first leaf (leaf i = f + 1 runs at lvl0 ^ (i & 1)); it alternates
             for (uint32_t j = 0; __ballot(walker && j < left) != 0; ++j) {
                 if (walker && j < left) {
-                    const uint32_t lvbase = (((f0 + c0 + j + 1u) & 1u) ^ lvl0) ? nbp0 : 0u;
-                    const uint32_t z = zq[j];
+                    const uint32_t rz = zq[j];                  // where the leaf's row set starts (scan_sync_kernel)
                     plane[c0 + j] = (uint16_t)(cur | (nb << 7));
-                    const bool plain = cur < S && z != kSyncNone;
-                    uint32_t q = g_mr[rows2 + __umul24(lvbase + (plain ? z : 0u), twoS) + 2u * min(cur, S - 1u) + (nb >= max_bits ? 1u : 0u)];
+                    const bool plain = cur < S && rz != kSyncNone;
+                    uint32_t q = g_mr[rows2 + (plain ? rz : 0u) + 2u * min(cur, S - 1u) + (nb >= max_bits ? 1u : 0u)];
                     q = plain ? q : 0u;
                     if ((int32_t)q < 0) {
                         // state' | bit count (absolute) or bits appended (relative) << 8
@@ -2520,6 +2527,7 @@ __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
         }
         const uint32_t s = cur < S ? __umul24(cur, NB1) + nb : (cur == S ? SNB + nb : nb);
         // ---- where the walk arrived ----------------------------------------------------------------------------
+        uint32_t mine = 0;
         if (walker) {
             uint32_t arrive = 0;
             if (stop) {
@@ -2547,10 +2555,15 @@ __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
             }
             if (bad && !stop && sp.f.debug) sp.f.debug[63] = gb | ((uint64_t)lb << 32);
             // (16-bit stores: the candidates of a block write the halves of the same words)
-            reinterpret_cast<uint16_t *>(rec + kSyncRecMap)[k] = (uint16_t)(arrive | (stop ? 0u : 0x8000u));
             reinterpret_cast<uint16_t *>(rec + kSyncRecEnd)[k] = (uint16_t)s;
             if (bad) atomicOr(sp.sync_fail, 1u);
+            mine = (arrive | (stop ? 0u : 4u)) << (3u * k);
         }
+        // the slot's digest: its candidates' three bits each, gathered over its eight lanes
+        mine |= (uint32_t)__shfl_xor((int)mine, 1);
+        mine |= (uint32_t)__shfl_xor((int)mine, 2);
+        mine |= (uint32_t)__shfl_xor((int)mine, 4);
+        if (region && k == 0) sp.sync_dig[gb] = (info & 0x7fu) | 0x80u | (info & 0x700u) | (mine << kSyncDigMap);
     }
 }
 
@@ -2564,68 +2577,89 @@ __device__ __forceinline__ uint32_t sync_map_then(uint32_t a, uint32_t b) {
     for (uint32_t x = 0; x < kSyncK; ++x) r |= sync_map_apply(b, sync_map_apply(a, x) & 3u) << (8u * x);
     return r;
 }
-// blocks per thread of scan_syncpick_kernel, at most: their records are fetched in ONE round trip and kept in
-// registers (1024 threads: captures up to 1.5 M edges; beyond, the composing kernels)
+// blocks per thread of scan_syncpick_kernel, at most (1024 threads: captures up to 1.5 M edges; beyond, the
+// composing kernels).  The digests of a capture's blocks go through the LDS: fetched and stored in order, coalesced
+// (a thread reading its own run of 32-byte records from memory touched a cache line per lane and word: 73 000 line
+// requests from one CU, 32 us), read and rewritten there by the thread that owns the run.
 constexpr uint32_t kPickPer = 24;
+
+__device__ __forceinline__ uint32_t sync_dig_map(uint32_t dig) {
+    const uint32_t mb = dig >> kSyncDigMap;
+    return (mb & 3u) | (((mb >> 3) & 3u) << 8) | (((mb >> 6) & 3u) << 16) | (((mb >> 9) & 3u) << 24);
+}
 
 __global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
-    __shared__ uint32_t maps[2][kScanThreads];
+    __shared__ uint32_t maps[2][kScanThreads / 64];
     __shared__ uint32_t lastc[kScanThreads];
-    if (*sp.fallback || (*sp.sync_fail & 1u)) return;
+    uint32_t *const dig = reinterpret_cast<uint32_t *>(scan_smem);          // [kPickPer * kScanThreads]
     const uint32_t tid = threadIdx.x;
+    if (*sp.fallback) return;
+    if (*sp.sync_fail & 1u) {
+        // no composing kernels behind this launch: the run is refused, the host queues it again with them
+        if (sp.sync_only && tid == 0) atomicOr(sp.fallback, (uint32_t)kFbSync);
+        return;
+    }
     for (uint32_t cap = blockIdx.x; cap < sp.f.num_captures; cap += gridDim.x) {
         const uint32_t gb0 = sp.cap_block_off[cap], nblk = sp.cap_block_off[cap + 1] - gb0;
         const uint32_t per = (nblk + kScanThreads - 1) / kScanThreads;
         if (per > kPickPer) {                   // (uniform: every thread leaves)
-            if (tid == 0) atomicOr(sp.sync_fail, 1u);
+            if (tid == 0) {
+                atomicOr(sp.sync_fail, 1u);
+                if (sp.sync_only) atomicOr(sp.fallback, (uint32_t)kFbSync);
+            }
             return;
         }
-        const uint32_t b0 = min(tid * per, nblk);
-        uint32_t *const rec0 = sp.sync_rec + (size_t)(gb0 + b0) * kSyncRecWords;
-        uint32_t info[kPickPer], m01[kPickPer], m23[kPickPer];
-#pragma unroll
-        for (uint32_t j = 0; j < kPickPer; ++j) {
-            const bool in = j < per && b0 + j < nblk;
-            const uint32_t *rec = rec0 + (size_t)j * kSyncRecWords;
-            info[j] = in ? rec[kSyncRecInfo] : 0u;
-            m01[j] = in ? rec[kSyncRecMap] : 0u;
-            m23[j] = in ? rec[kSyncRecMap + 1] : 0u;
-        }
+        for (uint32_t i = tid; i < nblk; i += kScanThreads) dig[i] = sp.sync_dig[gb0 + i];
+        __syncthreads();
+        const uint32_t b0 = min(tid * per, nblk), b1 = min(b0 + per, nblk);
         // this thread's run of blocks as ONE map: candidate at the first region that starts at or behind b0 ->
         // candidate at the first region that starts behind the run (no region starts in the run: the same one)
         uint32_t m = sync_map_identity();
-#pragma unroll
-        for (uint32_t j = 0; j < kPickPer; ++j) {
-            if (info[j] & 0x8000u)
-                m = sync_map_then(m, (m01[j] & 3u) | (((m01[j] >> 16) & 3u) << 8) | ((m23[j] & 3u) << 16) | (((m23[j] >> 16) & 3u) << 24));
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t d = dig[b];
+            if (d & 0x80u) m = sync_map_then(m, sync_dig_map(d));
         }
-        // inclusive scan of the maps by doubling
-        uint32_t cur = 0;
-        maps[0][tid] = m;
+        // exclusive scan of the maps: inside the waves by shuffles, the sixteen wave totals by the first wave
+        const uint32_t lane = tid & 63u, wv = tid >> 6;
+        uint32_t incl = m;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_up((int)incl, (int)d);
+            if (lane >= d) incl = sync_map_then(other, incl);
+        }
+        if (lane == 63) maps[0][wv] = incl;
         __syncthreads();
-        for (uint32_t d = 1; d < (uint32_t)kScanThreads; d <<= 1) {
-            const uint32_t mine = maps[cur][tid];
-            maps[cur ^ 1u][tid] = tid >= d ? sync_map_then(maps[cur][tid - d], mine) : mine;
-            cur ^= 1u;
-            __syncthreads();
-        }
-        // the capture's first region has one candidate (index 0): what it has become in front of this thread's run
-        uint32_t c = tid ? sync_map_apply(maps[cur][tid - 1], 0u) & 3u : 0u;
-        // the run again: every region's true candidate (two bits each)
-        uint64_t chosen = 0;
-        uint32_t last = 0xffffffffu;
+        if (wv == 0) {
+            uint32_t t = lane < (uint32_t)(kScanThreads / 64) ? maps[0][lane] : sync_map_identity();
 #pragma unroll
-        for (uint32_t j = 0; j < kPickPer; ++j) {
-            if (info[j] & 0x8000u) {
-                chosen |= (uint64_t)c << (2u * j);
+            for (uint32_t d = 1; d < (uint32_t)(kScanThreads / 64); d <<= 1) {
+                const uint32_t other = (uint32_t)__shfl_up((int)t, (int)d);
+                if (lane >= d) t = sync_map_then(other, t);
+            }
+            if (lane < (uint32_t)(kScanThreads / 64)) maps[1][lane] = t;        // inclusive over the waves
+        }
+        __syncthreads();
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) excl = sync_map_identity();
+        if (wv) excl = sync_map_then(maps[1][wv - 1], excl);
+        // the capture's first region has one candidate (index 0): what it has become in front of this thread's run
+        uint32_t c = sync_map_apply(excl, 0u) & 3u;
+        // the run again: every region's true candidate, left in its digest's place (| 0x80)
+        uint32_t last = 0xffffffffu;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t d = dig[b];
+            if (d & 0x80u) {
                 last = c;
-                const uint32_t me = ((c & 2u) ? m23[j] : m01[j]) >> (16u * (c & 1u));
-                if (me & 0x8000u) {             // its walk reached the end of the capture: the state behind the last leaf
-                    const uint32_t e = rec0[(size_t)j * kSyncRecWords + kSyncRecEnd + (c >> 1)];
+                const uint32_t me = (d >> (kSyncDigMap + 3u * c)) & 7u;
+                if (me & 4u) {                  // its walk reached the end of the capture: the state behind the last leaf
+                    const uint32_t e = sp.sync_rec[(size_t)(gb0 + b) * kSyncRecWords + kSyncRecEnd + (c >> 1)];
                     sp.cap_end[cap] = (uint16_t)((e >> (16u * (c & 1u))) & 0xffffu);
                 }
+                dig[b] = (d & 0xffu) | (c << 12);
                 c = me & 3u;
+            } else {
+                dig[b] = 64u;                   // every leaf below the split
             }
         }
         // the plane of a block's leaves below its split is that of the region before: the last one that started
@@ -2639,20 +2673,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams 
                 break;
             }
         }
-#pragma unroll
-        for (uint32_t j = 0; j < kPickPer; ++j) {
-            if (j < per && b0 + j < nblk) {
-                uint32_t se;
-                if (info[j] & 0x8000u) {
-                    const uint32_t mine = (uint32_t)(chosen >> (2u * j)) & 3u;
-                    se = (info[j] & 0x7fu) | (before << 8) | (mine << 12);
-                    before = mine;
-                } else {
-                    se = 64u | (before << 8);   // every leaf below the split
-                }
-                rec0[(size_t)j * kSyncRecWords + kSyncRecSel] = se;
-            }
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint32_t d = dig[b];
+            dig[b] = (d & 0x7fu) | (before << 8) | (d & 0x3000u);
+            if (d & 0x80u) before = (d >> 12) & 3u;
         }
+        __syncthreads();
+        for (uint32_t i = tid; i < nblk; i += kScanThreads) sp.sync_sel[gb0 + i] = dig[i];
         __syncthreads();
     }
 }
@@ -2697,7 +2724,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     // (the walk from synchronising spans keeps a plane per candidate: scan_syncpick_kernel says which)
                     size_t plane = 0;
                     if (sync_form) {
-                        const uint32_t se = sp.sync_rec[(size_t)w * kSyncRecWords + kSyncRecSel];
+                        const uint32_t se = sp.sync_sel[w];
                         plane = (size_t)((l < (se & 0x7fu) ? se >> 8 : se >> 12) & 3u) * sp.pre_plane;
                     }
                     uint32_t in = sp.pre_codes[plane + (size_t)w * LB + l];
@@ -3663,6 +3690,8 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.super_tab = a.super_tab;
     sp.super_in = a.super_in;
     sp.sync_rec = a.sync_rec;
+    sp.sync_dig = a.sync_rec ? a.sync_rec + (size_t)(a.total_blocks_cap + 8) * kSyncRecWords : nullptr;
+    sp.sync_sel = a.sync_rec ? sp.sync_dig + a.total_blocks_cap + 8 : nullptr;
     sp.sync_fail = a.sync_fail;
     sp.sync_try = 0;
     sp.pre_plane = a.pre_plane;
@@ -3679,6 +3708,9 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_walk_kernel), lds_walk);
     if (e != hipSuccess) return e;
     e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_groups_kernel), lds_group);
+    if (e != hipSuccess) return e;
+    const size_t lds_pick = (size_t)kPickPer * kScanThreads * 4;
+    e = ensure_dynamic_lds(reinterpret_cast<const void *>(&scan_syncpick_kernel), lds_pick);
     if (e != hipSuccess) return e;
     // with span tables and 64-leaf blocks the leaf kernel runs one wave per block (OOKD_SCAN_LEAF=block: the
     // workgroup-per-block form, which is also what runs without span tables)
@@ -3746,28 +3778,30 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     // entry codes from synchronising spans first; the composing kernels behind them return at once unless that gave up
     sp.sync_try = (a.sync_try && wave_form && a.lt_merged && a.lt_sync_words && a.lt_sync_words <= kMergedLdsWords && a.rowz && a.skipc &&
                    a.pre_codes && a.pre_plane && a.sync_rec && a.sync_fail) ? 1u : 0u;
+    sp.sync_only = sp.sync_try && a.sync_try == 2 ? 1u : 0u;
     hipLaunchKernelGGL(scan_layout_kernel, dim3(1), dim3(kScanThreads), 0, stream, sp);
     if (sp.sync_try) {
         hipLaunchKernelGGL(scan_sync_kernel, dim3(512), dim3(256), 0, stream, sp);
         hipLaunchKernelGGL(scan_syncwalk_kernel, dim3(512), dim3(256), 0, stream, sp);
-        hipLaunchKernelGGL(scan_syncpick_kernel, dim3(cap_grid), dim3(kScanThreads), 0, stream, sp);
+        hipLaunchKernelGGL(scan_syncpick_kernel, dim3(cap_grid), dim3(kScanThreads), lds_pick, stream, sp);
     }
-    if (wave_form) {
-        hipLaunchKernelGGL(scan_leaf_wave_kernel, dim3(grid_env ? (uint32_t)atoi(grid_env) : wave_grid), dim3(64), lds_wave, stream, sp);
-    } else {
-        hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
+    // the composing kernels (with a walk in front of them they return at once unless it gave up; after a walk in
+    // sync_only form they are not queued at all: five launches less on the chain, ~25 us)
+    if (!(sp.sync_try && sp.sync_only)) {
+        if (wave_form) {
+            hipLaunchKernelGGL(scan_leaf_wave_kernel, dim3(grid_env ? (uint32_t)atoi(grid_env) : wave_grid), dim3(64), lds_wave, stream, sp);
+        } else {
+            hipLaunchKernelGGL(scan_leaf_kernel, dim3(leaf_blocks), dim3(kSimThreads), lds, stream, sp);
+        }
+        hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(kGroupsThreads), lds_group, stream, sp);
+        hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
+        // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables
+        sp.entry_phase = 0;
+        const bool with_phase2 = a.lt_off && a.lt_merged && a.rowz;
+        hipLaunchKernelGGL(scan_entry_kernel, dim3(kEntryP0Blocks + (with_phase2 ? 512u : 0u)), dim3(256), 0, stream, sp);
+        sp.entry_phase = 1;
+        hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
     }
-    hipLaunchKernelGGL(scan_groups_kernel, dim3(512), dim3(kGroupsThreads), lds_group, stream, sp);
-    hipLaunchKernelGGL(scan_walk_kernel, dim3(cap_grid), dim3(kScanThreads), lds_walk, stream, sp);
-    // entry codes of all blocks, then of all leaves, in two small passes; the emit kernel stages no tables
-    sp.pre_codes = a.pre_codes;
-    sp.blk_in = a.blk_in;
-    sp.rowz = a.rowz;
-    sp.entry_phase = 0;
-    const bool with_phase2 = a.lt_off && a.lt_merged && a.rowz;
-    hipLaunchKernelGGL(scan_entry_kernel, dim3(kEntryP0Blocks + (with_phase2 ? 512u : 0u)), dim3(256), 0, stream, sp);
-    sp.entry_phase = 1;
-    hipLaunchKernelGGL(scan_entry_kernel, dim3(512), dim3(256), 0, stream, sp);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(emit_blocks), dim3(kSimThreads), 0, stream, sp);
     // the finish workgroups wait for each other: no more of them than fit the chip at once
     hipLaunchKernelGGL(fin_write_kernel, dim3(256), dim3(kFinBlock), 0, stream, sp);

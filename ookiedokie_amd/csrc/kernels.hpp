@@ -384,9 +384,12 @@ struct FsmScanArgs {
     uint64_t pre_plane;         // pre_codes holds 4 planes this many elements apart (0: one plane, no such walk)
     uint32_t lt_sync_words;     // lt_merged's size with append_sync_codes' tables (lt_merged_words: the rows alone)
     uint32_t *sync_fail;        // device word, zero at launch: the walk from the synchronising spans gave up
-    uint32_t sync_try;          // try that walk first (needs the merged rows with append_sync_codes' words)
+    uint32_t sync_try;          // 1: try that walk first, the composing kernels queued behind it (they return at once unless
+                                // it gave up); 2: the walk alone -- giving up refuses the run with kScanFbSync and the host
+                                // queues it again with 0: the composing kernels only
 };
 
+constexpr uint32_t kScanFbSync = 16;      // refusal bit: the walk from synchronising spans gave up in a launch without composing kernels
 uint32_t fsm_scan_leaf_block(uint32_t D, uint32_t S, uint32_t SNB);
 // The trigger / state tables in the layout the scan kernels keep in LDS: size, and
 // a host-side fill (16-byte aligned destination) to be uploaded once per context.

@@ -373,6 +373,14 @@ struct ookd_rx {
     uint64_t pre_plane = 0;                 // elements per plane of d_pre (4 planes when that walk can run)
     uint32_t lt_merged_rows = 0;            // size of d_lt_merged without append_sync_codes' tables
     bool scan_sync = false;                 // try the walk from synchronising spans first
+    // How the next scan is queued.  The walk alone while it works (the composing kernels behind it would only return
+    // at once: five launches, ~25 us of the chain).  A run where it gives up is refused and queued again with the
+    // composing kernels only; so are the next kSyncBackoff - 1 runs, then one run carries both, and its verdict
+    // decides (a stream of captures of one kind settles in one form or the other).
+    static constexpr uint32_t kSyncBackoff = 8;
+    uint32_t sync_backoff = 0;              // runs left in the composing form
+    uint64_t sync_min_edges = 200000;       // edge lists expected shorter than this are composed (OOKD_SYNC_MIN_EDGES: tests)
+    uint32_t sync_mode = 0;                 // of the scan in flight: FsmScanArgs::sync_try
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
     bool front_grid = false;        // OOKD_RX_FRONT_GRID: one workgroup per wave tile instead of the streaming form
@@ -645,6 +653,17 @@ struct ookd_rx {
         return f;
     }
 
+    uint32_t next_sync_mode() {
+        if (!scan_sync) return sync_mode = 0;
+        // a short edge list goes through the composing kernels faster (their depth is what counts there: 152 against
+        // 160 us of chain for the 46 000 edges of a 1 GiB bench capture; 223 against 120 us for the 737 000 of 16 GiB):
+        // by the edge count of this context's last run -- before there is one, by the capture's length
+        const uint64_t expect = stats.num_edges ? stats.num_edges : ((uint64_t)run_n_out * run_caps) >> 12;
+        if (expect < sync_min_edges) return sync_mode = 0;
+        if (sync_backoff == 0) return sync_mode = 2;
+        return sync_mode = (--sync_backoff == 0) ? 1u : 0u;
+    }
+
     int front_and_edges(const void *d_iq, uint64_t stride, const int16_t *d_halo_ptr,
                         uint32_t halo_len);
     bool plan_chunks();
@@ -889,11 +908,11 @@ int ookd_rx::run_pipelined(const void *d_iq) {
     a.sync_rec = d_sync_rec.p;
     a.pre_plane = pre_plane;
     a.sync_fail = &d_hdr.p->sync_fail;
-    a.sync_try = scan_sync ? 1u : 0u;
+    a.sync_try = next_sync_mode();
         a.sync_rec = d_sync_rec.p;
         a.pre_plane = pre_plane;
         a.sync_fail = &d_hdr.p->sync_fail;
-        a.sync_try = scan_sync ? 1u : 0u;
+        a.sync_try = next_sync_mode();
         a.final_state = d_carry.p + (c & 1);
         a.fallback = &d_hdr.p->scan_fallback;
         a.fin_off = d_fin_off.p;
@@ -1209,7 +1228,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.sync_rec = d_sync_rec.p;
     a.pre_plane = pre_plane;
     a.sync_fail = &d_hdr.p->sync_fail;
-    a.sync_try = scan_sync ? 1u : 0u;
+    a.sync_try = next_sync_mode();
     a.fin_off = d_fin_off.p;
     a.fsum = d_fsum.p;
     a.fin_ticket = d_fin_tickets.p + kMaxChunks;
@@ -1313,12 +1332,29 @@ int ookd_rx::collect_results() {
             scan_used = true;
             stats.fsm_path = 1;
             stats.scan_entry_form = (h_hdr->sync_fail & 3u) == 2u ? 1u : 2u;
+            if (sync_mode == 1 && (h_hdr->sync_fail & 1u)) sync_backoff = kSyncBackoff;     // tried with both queued: not yet
             redo_some = run_caps > 1 && (h_hdr->flags & 2u) != 0;
+        } else if (h_hdr->scan_fallback == kScanFbSync && !h_hdr->edge_overflow && chunks.empty()) {
+            // the walk from synchronising spans gave up and nothing was queued behind it: the scan again, composing
+            // (and so for the next runs of this context)
+            sync_backoff = kSyncBackoff;
+            ResultHeader keep = *h_hdr;
+            keep.totals[0] = keep.totals[1] = 0;
+            keep.scan_fallback = 0;
+            keep.sync_fail = 0;
+            keep.publish_done = 0;          // (the scan's last kernel counts its workgroups here to find the one that publishes)
+            HIPCHK(hipMemcpyAsync(d_hdr.p, &keep, sizeof(keep), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hdr_dirty = true;
+            int rc = run_state_machine(pending_first_valid ? &pending_first : nullptr, true);
+            if (rc != OOKD_OK) return rc;
+            return fetch_results();
         } else if (h_hdr->edge_overflow) {
             // refused because the edge list overflowed: there is nothing to run the rounds on (blk_offset counts
             // edges that were never written); reported below
             stats.fsm_fallback_reason = h_hdr->scan_fallback;
         } else if (!chunks.empty()) {
+            if (h_hdr->scan_fallback & kScanFbSync) sync_backoff = kSyncBackoff;
             // the scan refused a chunk of a pipelined run: the whole capture again, unchunked (the
             // last chunk's publishing kernel left the device header zeroed)
             stats.fsm_fallback_reason = h_hdr->scan_fallback;
@@ -1754,6 +1790,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
                     const std::vector<uint16_t> masked(reach.begin(), reach.begin() + (reach.empty() ? 0 : rx->scan_reach_n));
                     append_sync_codes(merged, rx->scan_S, device->num_bits + 2, device->num_bits, masked);
                     rx->scan_sync = !(cfg->flags & OOKD_RX_SCAN_TABLES) && !dev_getenv("OOKD_SCAN_NO_SYNC");
+                    if (const char *e = dev_getenv("OOKD_SYNC_MIN_EDGES")) rx->sync_min_edges = strtoull(e, nullptr, 0);
                 }
                 rc |= rx->d_lt_merged.alloc(merged.size());
                 if (rc == OOKD_OK && hipMemcpy(rx->d_lt_merged.p, merged.data(), merged.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1793,7 +1830,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             rc |= rx->d_pre.alloc(((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64) * (rx->scan_sync ? 4 : 1));
             rc |= rx->d_rowz.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
             rc |= rx->d_skipc.alloc((size_t)rx->scan_blocks_cap * rx->scan_leaf_block + 64);
-            rc |= rx->d_sync_rec.alloc(((size_t)rx->scan_blocks_cap + 8) * 8);
+            rc |= rx->d_sync_rec.alloc(((size_t)rx->scan_blocks_cap + 8) * 10);     // records, digests, selections
             rc |= rx->d_blk_in.alloc((size_t)rx->scan_blocks_cap + 16);
             rc |= rx->d_final_state.alloc(caps);
             rx->scan_fin_cap = (uint32_t)((rx->edge_capacity + caps) / fsm_scan_fin_block() + caps + 8);

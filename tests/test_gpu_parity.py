@@ -8,6 +8,8 @@ import ctypes as C
 import json
 import os
 
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -49,6 +51,25 @@ def _odev(oracle, name, rate=RATE):
     return oracle.load_device_json(golden_path("devices", name), rate)[0]
 
 
+@contextlib.contextmanager
+def _sync_walk_forced(on=True):
+    """Receivers created inside try the scan's walk from synchronising spans whatever the expected edge count
+    (by default an edge list under 200 000 goes through the composing kernels)."""
+    keys = ("OOKD_DEVELOPER", "OOKD_SYNC_MIN_EDGES")
+    old = {k: os.environ.get(k) for k in keys}
+    if on:
+        os.environ["OOKD_DEVELOPER"] = "1"
+        os.environ["OOKD_SYNC_MIN_EDGES"] = "0"
+    try:
+        yield
+    finally:
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
+
+
 def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, check_fir=False,
              segment_buffers=0, rate=RATE, expect_scan=True):
     """Runs the capture through every form of the state machine (scan of
@@ -67,13 +88,17 @@ def _compare(ok, oracle, iq, filt, devname, spb=8192, thr=0.1, exact=False, chec
     # machine of chunk c, state carried on the device) and with the packed-VALU form of the 1-stage
     # front end instead of the matrix-core one (the default wherever it applies); and the scan with its entry
     # states from composed block tables only (the default first tries the walk from synchronising spans)
+    # (tables: None = the default -- composed for an edge list as short as a test's --, True = OOKD_RX_SCAN_TABLES,
+    #  False = the walk from synchronising spans whatever the length)
     for fsm_rounds, scan_sims, chunk, valu, tables in (
-            (False, False, 0, False, False), (False, True, 0, False, False), (True, False, 0, False, False),
-            (False, False, 4 * spb, False, False), (False, False, 0, True, False), (False, False, 0, False, True)):
-        rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
-                         exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
-                         fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims,
-                         pipeline_chunk_samples=chunk, fir_valu=valu, scan_tables=tables)
+            (False, False, 0, False, None), (False, True, 0, False, None), (True, False, 0, False, None),
+            (False, False, 4 * spb, False, None), (False, False, 0, True, None), (False, False, 0, False, True),
+            (False, False, 0, False, False), (False, False, 4 * spb, False, False)):
+        with _sync_walk_forced(tables is False):
+            rx = ok.Receiver(f, d, max_samples=max(n, 1), threshold=thr, samples_per_buffer=spb,
+                             exact_fir=exact, keep_fir=check_fir, segment_buffers=segment_buffers,
+                             fsm_rounds=fsm_rounds, quiet_skip=not fsm_rounds, scan_sims=scan_sims,
+                             pipeline_chunk_samples=chunk, fir_valu=valu, scan_tables=bool(tables))
         got = rx.rx(iq)
         assert got.stats["decimated_samples"] == want.decimated
         if tables and got.stats["fsm_path"] == 1:
@@ -1234,3 +1259,53 @@ def test_edge_list_overflow_with_a_state_machine_is_refused_cleanly(ok, oracle, 
         assert list(good.edges()) == list(edges_of(want.bits))
     small.close()
     good.close()
+
+
+# ------------------------------------------------- walk from synchronising spans ----
+
+@pytest.mark.parametrize("devname,kw", [("p3l-nexa2012", {}), ("p3l-nexa2012", dict(glitch_every=5)),
+                                        ("p3l-nexa2012", dict(gap_us=(17000, 30000))), ("unknown-remote1", {}),
+                                        ("unknown-remote1", dict(glitch_every=7, noise=120))])
+def test_scan_walk_from_synchronising_spans(ok, oracle, devname, kw):
+    """Captures with silence between the messages: the scan finds every leaf's entry state by walking from one
+    synchronising span to the next (stats.scan_entry_form 1) -- messages, payloads and errors are the oracle's, and
+    those of the composing kernels (OOKD_RX_SCAN_TABLES)."""
+    n = 1 << 24
+    d = _dev(ok, devname)
+    od = _odev(oracle, devname)
+    iq = ok.Synth(d, n, seed=11, sample_rate=RATE, **kw).fill_host()
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, od, 8192, want_bits=False)
+    res = {}
+    for tables in (False, True):
+        with _sync_walk_forced(not tables):
+            rx = ok.Receiver(_flt(ok, "fs32_fs4"), d, max_samples=n, scan_tables=tables)
+        for _ in range(2):              # (the second run of a context: stamps, counters and tickets of the first behind it)
+            got = rx.rx(iq)
+        assert got.stats["fsm_path"] == 1 and got.stats["scan_entry_form"] == (2 if tables else 1), got.stats
+        assert list(got.msg_samples) == list(want.msg_samples)
+        assert (got.payloads == want.payloads).all()
+        errs, nerr = rx.errors()
+        assert nerr == len(want.err_samples) and list(errs[:32]) == list(want.err_samples[:32])
+        res[tables] = got
+        rx.close()
+    assert len(want.msg_samples) >= 20
+
+
+def test_scan_walk_gives_up_and_the_scan_composes(ok, oracle):
+    """Gaps too short to synchronise anything (under the longest time-out): the walk gives up -- alone in its launch
+    the first time, so the run is queued again with the composing kernels; then composed for a few runs; then one
+    run carries both forms and the verdict stands.  Every run decodes what the oracle does."""
+    n = 1 << 25
+    d = _dev(ok, "p3l-nexa2012")
+    od = _odev(oracle, "p3l-nexa2012")
+    iq = ok.Synth(d, n, seed=12, sample_rate=RATE, gap_us=(4000, 5500), glitch_every=0).fill_host()
+    want = oracle.rx(iq, _ofir(oracle, "fs32_fs4"), 0.1, od, 8192, want_bits=False)
+    with _sync_walk_forced():
+        rx = ok.Receiver(_flt(ok, "fs32_fs4"), d, max_samples=n)
+    for run in range(11):
+        got = rx.rx(iq)
+        assert got.stats["fsm_path"] == 1 and got.stats["scan_entry_form"] == 2, (run, got.stats)
+        assert list(got.msg_samples) == list(want.msg_samples), run
+        assert (got.payloads == want.payloads).all(), run
+        assert rx.errors()[1] == len(want.err_samples), run
+    rx.close()

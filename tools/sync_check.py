@@ -6,6 +6,9 @@
 import os
 import sys
 
+os.environ["OOKD_DEVELOPER"] = "1"
+os.environ["OOKD_SYNC_MIN_EDGES"] = "0"      # the walk whatever the edge count (default: from 200 000 edges on)
+
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
