@@ -228,32 +228,34 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const EdgeParams p) {
 }
 
 // The same behind the tuned front-end kernels, which leave a count of level changes per wave
-// tile: ONE LANE per 4096-bit block.  The lanes of a wave read their blocks' offsets / counts
-// and tile infos coalesced, add the group base, and only a block's tiles that hold a change have
-// their words read (8 or 16 words) -- a capture is mostly constant level, so that is a few
-// percent of the bit words, where edge_write_kernel reads every word of every block that
-// holds an edge.  Positions come out ascending: tiles in order, words in order, bits in order.
+// tile: ONE LANE per wave tile (round 3; one lane per 4096-bit block of 4, 8 or 16 tiles before).
+// The lanes of a block sit next to each other in a wave: each reads the block's offset / count
+// and its tile infos (the same 16-byte pieces: one request per block), adds up what the tiles in
+// front of its own hold, and only a lane whose tile holds a change reads the tile's words (4, 8
+// or 16 of them, one go) -- a capture is mostly constant level, so that is a few percent of the
+// bit words, where edge_write_kernel reads every word of every block that holds an edge.
+// Positions come out ascending: tiles in order, words in order, bits in order.  (A lane per block
+// went through its loud tiles one after the other -- up to four dependent trips to memory where a
+// message keeps every tile of every block of a wave busy: 50 us at 16 GiB.)
 template <uint32_t TPB>
 __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams p) {
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t tpb = TPB;           // wave tiles per 4096-bit block: 4, 8 or 16 (compile time: everything unrolls)
+    const uint32_t b = gid / tpb, t = gid % tpb;
     const uint32_t total_blocks = p.num_captures * p.blocks_per_cap;
     if (b >= total_blocks) return;
     const uint32_t cap = b / p.blocks_per_cap, blk = b - cap * p.blocks_per_cap;
-    constexpr uint32_t tpb = TPB;           // wave tiles per 4096-bit block: 4, 8 or 16 (compile time: everything unrolls)
     constexpr uint32_t words_per_tile = (uint32_t)kBlockWords / tpb;
     constexpr uint32_t tile_bits = words_per_tile * 64u;
     const uint32_t *ti = p.tile_info + (uint64_t)cap * p.blocks_per_cap * tpb;
     const uint64_t *words = p.bits + (uint64_t)cap * p.words_per_cap;
     const uint32_t t0 = blk * tpb;
-    // Few round trips to memory per lane (the kernel is latency times rounds of waves): the block's offset, count AND
-    // tile infos (4, 8 or 16 dwords = 1, 2 or 4 16-byte loads) in ONE go -- the infos of a block without an edge
-    // are 16 MB per 16 GiB capture read for nothing, and one dependent round trip less for every block that has
-    // one --, then every loud tile's words in one go (64 bytes).
+    // one round trip: the block's offset, count and tile infos (and the info of the tile in front of the block)
     uint32_t infos[tpb];
+    const uint32_t off_local = p.blk_offset[b], gbase = p.group_total[b / kScanGroup], cnt = p.blk_count[b];
+    const uint32_t prev_info = (t0 || p.has_prev) ? *(ti + t0 - 1) : 0u;
     {
-        const uint32_t off_local = p.blk_offset[b], gbase = p.group_total[b / kScanGroup], cnt = p.blk_count[b];
-        const uint32_t prev_info = (t0 || p.has_prev) ? *(ti + t0 - 1) : 0u;
         const uint4 *ti4 = reinterpret_cast<const uint4 *>(ti + t0);
 #pragma unroll
         for (uint32_t q = 0; q < tpb / 4; ++q) {
@@ -263,41 +265,48 @@ __global__ __launch_bounds__(256) void edge_write_tiles_kernel(const EdgeParams 
             infos[4 * q + 2] = v.z;
             infos[4 * q + 3] = v.w;
         }
-        const uint32_t off = off_local + gbase;
-        p.blk_offset[b] = off;
-        if (cnt == 0) return;
-        uint32_t prev_last = (t0 || p.has_prev) ? tile_live(prev_info, p.stamp_bits) >> 31 : 0u;
-        uint64_t at = off;
+    }
+    const uint32_t off = off_local + gbase;
+    // (the block's lanes are neighbours in one wave: all of them have read the local offset before this store)
+    if (t == 0) p.blk_offset[b] = off;
+    if (cnt == 0) return;
+    // what the tiles in front of this one hold, and the level in front of it
+    uint32_t prev_last = (t0 || p.has_prev) ? tile_live(prev_info, p.stamp_bits) >> 31 : 0u;
+    uint64_t at = off;
+    uint32_t mine = 0, carry0 = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < tpb; ++t) {
-            const bool live = (uint64_t)(t0 + t) * tile_bits < p.n_out;
-            const uint32_t info = live ? tile_live(infos[t], p.stamp_bits) : 0u;
-            const uint32_t c = live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
-            if (c) {
-                const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
-                // the tile's words (4, 8 or 16 of them), requested together
-                uint4 wv[words_per_tile / 2];
-                const uint4 *w4 = reinterpret_cast<const uint4 *>(words + w0);
+    for (uint32_t q = 0; q < tpb; ++q) {
+        const bool live = (uint64_t)(t0 + q) * tile_bits < p.n_out;
+        const uint32_t info = live ? tile_live(infos[q], p.stamp_bits) : 0u;
+        const uint32_t c = live ? (info & 0x3ffu) + (((info >> 30) & 1u) ^ prev_last) : 0u;
+        if (q < t) at += c;
+        if (q == t) {
+            mine = c;
+            carry0 = prev_last;
+        }
+        prev_last = live ? info >> 31 : prev_last;
+    }
+    if (mine == 0) return;
+    const uint64_t w0 = (uint64_t)(t0 + t) * words_per_tile;
+    // the tile's words (4, 8 or 16 of them), requested together
+    uint4 wv[words_per_tile / 2];
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(words + w0);
 #pragma unroll
-                for (uint32_t q = 0; q < words_per_tile / 2; ++q) wv[q] = w4[q];
-                uint64_t carry = prev_last;
+    for (uint32_t q = 0; q < words_per_tile / 2; ++q) wv[q] = w4[q];
+    uint64_t carry = carry0;
 #pragma unroll
-                for (uint32_t i = 0; i < words_per_tile; ++i) {
-                    const uint4 v = wv[i >> 1];
-                    const uint64_t cur = (i & 1u) ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
-                    uint64_t e = cur ^ ((cur << 1) | carry);
-                    carry = cur >> 63;
-                    const uint64_t base = (w0 + i) * 64;
-                    if (base + 64 > p.n_out) e &= base >= p.n_out ? 0ull : ((1ull << (p.n_out - base)) - 1ull);
-                    while (e) {
-                        const int bit = __ffsll((long long)e) - 1;
-                        if (at < p.edge_capacity) p.edges[at] = base + (uint64_t)bit;
-                        ++at;
-                        e &= e - 1;
-                    }
-                }
-            }
-            prev_last = live ? info >> 31 : prev_last;
+    for (uint32_t i = 0; i < words_per_tile; ++i) {
+        const uint4 v = wv[i >> 1];
+        const uint64_t cur = (i & 1u) ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
+        uint64_t e = cur ^ ((cur << 1) | carry);
+        carry = cur >> 63;
+        const uint64_t base = (w0 + i) * 64;
+        if (base + 64 > p.n_out) e &= base >= p.n_out ? 0ull : ((1ull << (p.n_out - base)) - 1ull);
+        while (e) {
+            const int bit = __ffsll((long long)e) - 1;
+            if (at < p.edge_capacity) p.edges[at] = base + (uint64_t)bit;
+            ++at;
+            e &= e - 1;
         }
     }
 }
@@ -1094,7 +1103,7 @@ hipError_t launch_edges(const EdgeParams &p, hipStream_t stream) {
     hipLaunchKernelGGL(edge_scan_local_kernel, dim3(groups), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(edge_scan_groups_kernel, dim3(1), dim3(1024), 0, stream, p);
     if (p.tile_info) {
-        const dim3 grid((total_blocks + 255) / 256);
+        const dim3 grid((uint32_t)(((uint64_t)total_blocks * p.tiles_per_block + 255) / 256));      // a lane per tile
         if (p.tiles_per_block == 4) hipLaunchKernelGGL(edge_write_tiles_kernel<4>, grid, dim3(256), 0, stream, p);
         else if (p.tiles_per_block == 8) hipLaunchKernelGGL(edge_write_tiles_kernel<8>, grid, dim3(256), 0, stream, p);
         else if (p.tiles_per_block == 16) hipLaunchKernelGGL(edge_write_tiles_kernel<16>, grid, dim3(256), 0, stream, p);

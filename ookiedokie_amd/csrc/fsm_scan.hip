@@ -2412,7 +2412,7 @@ __device__ __forceinline__ void sync_split(uint32_t code, uint32_t SNB, uint32_t
 __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ LTab T;
-    __shared__ uint16_t s_z[4][8][64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_z[4][8][64];
     __shared__ uint32_t s_sk[4][8][64];
     const uint32_t noff = 2 * (2 * sp.S + 2) + 1, nint = (sp.lt_words - noff) / 2u;
     stage_sync_tables(sp, T, noff, nint);
@@ -2499,27 +2499,35 @@ __global__ __launch_bounds__(256) void scan_syncwalk_kernel(ScanParams sp) {
             }
             wave_sync_lds();
             const uint32_t left = len > c0 ? min(len - c0, 64u) : 0u;
-            for (uint32_t j = 0; __ballot(walker && j < left) != 0; ++j) {
-                if (walker && j < left) {
-                    const uint32_t rz = zq[j];                  // where the leaf's row set starts (scan_sync_kernel)
-                    plane[c0 + j] = (uint16_t)(cur | (nb << 7));
-                    const bool plain = cur < S && rz != kSyncNone;
-                    uint32_t q = g_mr[rows2 + (plain ? rz : 0u) + 2u * min(cur, S - 1u) + (nb >= max_bits ? 1u : 0u)];
-                    q = plain ? q : 0u;
-                    if ((int32_t)q < 0) {
-                        // state' | bit count (absolute) or bits appended (relative) << 8
-                        nb = min(((q & 0x40000000u) ? nb : 0u) + ((q >> 8) & 0xffffu), NB1 - 1u);
-                        cur = q & 0xffu;
-                    } else {
-                        // skip codes: scan_sync_kernel's skip rows; stuck codes, rows that need a simulation: the full step
-                        uint32_t code = cur < S ? __umul24(cur, NB1) + nb : (cur == S ? SNB + nb : nb);
-                        if (cur == S && nb < 2u) {
-                            code = (skq[j] >> (16u * nb)) & 0xffffu;
+            // eight steps at a time: their row offsets in ONE 16-byte read, off the chain of dependent reads (a step
+            // is then one read of the row entry the state selects, and its decode)
+            for (uint32_t j0 = 0; __ballot(walker && j0 < left) != 0; j0 += 8) {
+                const uint4 r8 = *reinterpret_cast<const uint4 *>(zq + j0);
+                const uint32_t rr[4] = {r8.x, r8.y, r8.z, r8.w};
+#pragma unroll
+                for (uint32_t jj = 0; jj < 8; ++jj) {
+                    const uint32_t j = j0 + jj;
+                    if (walker && j < left) {
+                        const uint32_t rz = (rr[jj >> 1] >> (16u * (jj & 1u))) & 0xffffu;   // where the leaf's row set starts
+                        plane[c0 + j] = (uint16_t)(cur | (nb << 7));
+                        const bool plain = cur < S && rz != kSyncNone;
+                        uint32_t q = g_mr[rows2 + (plain ? rz : 0u) + 2u * min(cur, S - 1u) + (nb >= max_bits ? 1u : 0u)];
+                        q = plain ? q : 0u;
+                        if ((int32_t)q < 0) {
+                            // state' | bit count (absolute) or bits appended (relative) << 8
+                            nb = min(((q & 0x40000000u) ? nb : 0u) + ((q >> 8) & 0xffffu), NB1 - 1u);
+                            cur = q & 0xffu;
                         } else {
-                            const uint32_t f = f0 + c0 + j;             // leaf i = f + 1 of the capture
-                            code = leaf_step_fly_g(T, sc, noff, nint, (uint64_t)f + 1u, edges[f], edges[f + 1u], code);
+                            // skip codes: scan_sync_kernel's skip rows; stuck codes, rows that need a simulation: the full step
+                            uint32_t code = cur < S ? __umul24(cur, NB1) + nb : (cur == S ? SNB + nb : nb);
+                            if (cur == S && nb < 2u) {
+                                code = (skq[j] >> (16u * nb)) & 0xffffu;
+                            } else {
+                                const uint32_t f = f0 + c0 + j;         // leaf i = f + 1 of the capture
+                                code = leaf_step_fly_g(T, sc, noff, nint, (uint64_t)f + 1u, edges[f], edges[f + 1u], code);
+                            }
+                            sync_split(code, SNB, NB1, S, rcpNB1, cur, nb);
                         }
-                        sync_split(code, SNB, NB1, S, rcpNB1, cur, nb);
                     }
                 }
             }

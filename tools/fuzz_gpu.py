@@ -4,7 +4,11 @@ per-span simulation, rounds) against the CPU oracle on message-like streams whos
 lengths sit on and around the devices' tolerance windows, with glitches, for several sample
 rates and buffer sizes.  Not part of the test suite (minutes); prints a JSON summary.
 
-    python tools/fuzz_gpu.py [--seconds 300] [--seed 1]
+    python tools/fuzz_gpu.py [--seconds 300] [--seed 1] [--sync-walk]
+
+--sync-walk: the scan's default legs find the entry states by the walk from synchronising spans whatever the edge
+count (by default only edge lists of 200 000 and more do), and one more leg runs the composing kernels
+(OOKD_RX_SCAN_TABLES); the summary counts which form each run ended in (scan_entry_form).
 """
 import argparse
 import json
@@ -127,6 +131,9 @@ def random_device_case(rng, stats):
             rx.close()
             continue
         stats["receivers"] += 1
+        if not fsm_rounds and not scan_sims and got.stats["fsm_path"] == 1:
+            key = "random_device_entry_form_%d" % got.stats["scan_entry_form"]
+            stats[key] = stats.get(key, 0) + 1
         if not fsm_rounds:
             stats["scan_runs"] += 1
             if got.stats["fsm_path"] != 1:
@@ -158,7 +165,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--cases", type=int, default=0, help="stop after this many captures (0 = run for --seconds)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sync-walk", action="store_true")
     args = ap.parse_args()
+    if args.sync_walk:
+        os.environ["OOKD_DEVELOPER"] = "1"
+        os.environ["OOKD_SYNC_MIN_EDGES"] = "0"
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
     stats = dict(cases=0, receivers=0, messages=0, errors=0, scan_runs=0, scan_refused=0, refusals={}, mismatches=[])
@@ -192,12 +203,18 @@ def main():
         stats["errors"] += len(want.err_samples)
         # scan with span tables / with per-span simulation, rounds, and the scan pipelined in chunks of a few
         # buffers (state carried on the device)
-        for fsm_rounds, scan_sims, chunk in ((False, False, 0), (False, True, 0), (True, False, 0),
-                                             (False, False, int(rng.choice([2, 4, 16])) * spb)):
+        legs = [(False, False, 0, False), (False, True, 0, False), (True, False, 0, False),
+                (False, False, int(rng.choice([2, 4, 16])) * spb, False)]
+        if args.sync_walk:
+            legs.append((False, False, 0, True))
+        for fsm_rounds, scan_sims, chunk, tables in legs:
             rx = ok.Receiver(f, d, max_samples=iq.size // 2, samples_per_buffer=spb, fsm_rounds=fsm_rounds,
-                             quiet_skip=not fsm_rounds, scan_sims=scan_sims, pipeline_chunk_samples=chunk)
+                             quiet_skip=not fsm_rounds, scan_sims=scan_sims, pipeline_chunk_samples=chunk, scan_tables=tables)
             got = rx.rx(iq)
             stats["receivers"] += 1
+            if not fsm_rounds and not scan_sims and not tables and got.stats["fsm_path"] == 1:
+                key = "entry_form_%d%s" % (got.stats["scan_entry_form"], "_pipelined" if got.stats["pipeline_chunks"] else "")
+                stats[key] = stats.get(key, 0) + 1
             if chunk:
                 stats["pipelined"] = stats.get("pipelined", 0) + (1 if got.stats["pipeline_chunks"] else 0)
                 stats["pipelined_refused"] = stats.get("pipelined_refused", 0) + (
@@ -214,7 +231,8 @@ def main():
                     and (nerr > 32 or list(errs) == list(want.err_samples)))
             if not good:
                 stats["mismatches"].append(dict(device=name, rate=rate, filter=fname, spb=spb, runs=[int(r) for r in runs],
-                                                fsm_rounds=fsm_rounds, scan_sims=scan_sims, chunk=chunk,
+                                                fsm_rounds=fsm_rounds, scan_sims=scan_sims, chunk=chunk, tables=tables,
+                                                entry_form=int(got.stats["scan_entry_form"]),
                                                 want=[int(x) for x in want.msg_samples],
                                                 got=[int(x) for x in got.msg_samples]))
             rx.close()
