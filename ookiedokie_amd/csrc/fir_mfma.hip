@@ -206,15 +206,23 @@ struct MfmaTileCtx {            // uniform per workgroup
     uint32_t *ctl;              // LDS: [0] next ticket, [1] image ready
     uint32_t tickets;           // per workgroup
     uint64_t tile_base, tile_end;
+    uint32_t xcd_span;          // != 0: the launch's tiles in eight runs of this many, one per XCD (see mfma_take_ticket)
     bool aligned16;
 };
 
+// Ticket tk of workgroup b is position v = tk * gridDim + b of the launch: workgroups that run at the same time hold
+// neighbouring positions.  Position -> tile: v itself -- or, xcd_span != 0 (the launch holds 8 * xcd_span tiles):
+// tile (v & 7) * xcd_span + (v >> 3).  Workgroups are dealt out to the eight XCDs in turn, so v & 7 is the XCD: each
+// XCD then goes through ONE contiguous eighth of the launch, and the halo a tile shares with the next one (96 of 1120
+// samples for the decimate-by-4 filter) is read by the same XCD twice -- the second time from its L2 -- instead of by
+// two XCDs from memory once each.
 __device__ __forceinline__ bool mfma_take_ticket(const MfmaTileCtx &c, uint32_t tid, uint64_t &tile) {
     uint32_t tk = 0;
     if (tid == 0) tk = __hip_atomic_fetch_add(&c.ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    tile = (uint64_t)tk * gridDim.x + blockIdx.x + c.tile_base;
-    return tk < c.tickets && tile < c.tile_end;
+    const uint64_t v = (uint64_t)tk * gridDim.x + blockIdx.x;
+    tile = (c.xcd_span ? (v & 7u) * (uint64_t)c.xcd_span + (v >> 3) : v) + c.tile_base;
+    return tk < c.tickets && v + c.tile_base < c.tile_end;
 }
 
 template <int KS>
@@ -368,6 +376,7 @@ void fir1_mfma_kernel(const FrontParams p) {
     c.tickets = p.mfma_g * (uint32_t)kMfmaWaves;
     c.tile_base = p.tile_base;
     c.tile_end = p.tile_end;
+    c.xcd_span = p.mfma_xcd_span;
     c.aligned16 = (((uintptr_t)c.rs.src & 15u) == 0);
     typedef __attribute__((address_space(1))) uint64_t *gptr64;
     typedef __attribute__((address_space(1))) uint32_t *gptr32w;
@@ -727,6 +736,7 @@ void fir2_mfma_kernel(const FrontParams p) {
     c.tickets = p.mfma_g * (uint32_t)kF2Waves;
     c.tile_base = p.tile_base;
     c.tile_end = p.tile_end;
+    c.xcd_span = p.mfma_xcd_span;
     c.aligned16 = (((uintptr_t)c.rs.src & 15u) == 0);
     F2Taps ft;
     ft.taps1 = (gptrf)(p.taps + p.stage[0].tap_off);
@@ -1085,6 +1095,7 @@ hipError_t launch_front_mfma2(const FrontParams &p, uint32_t num_captures, hipSt
     pp.tile_base = (uint32_t)b;
     pp.tile_end = b + cnt;
     if (pp.mfma_g == 0) pp.mfma_g = 1;
+    pp.mfma_xcd_span = (p.mfma_xcd & 2u) && cnt % 8 == 0 && cnt / 8 <= 0xffffffffull ? (uint32_t)(cnt / 8) : 0u;
     const uint64_t grid = (cnt + (uint64_t)pp.mfma_g * kF2Waves - 1) / ((uint64_t)pp.mfma_g * kF2Waves);
     const void *fn = reinterpret_cast<const void *>(&fir2_mfma_kernel);
     hipError_t e = ensure_dynamic_lds(fn, kF2LdsBytes);
@@ -1119,6 +1130,7 @@ hipError_t launch_front_mfma(const FrontParams &p, uint32_t num_captures, hipStr
     pp.tile_base = (uint32_t)b;
     pp.tile_end = b + cnt;
     if (pp.mfma_g == 0) pp.mfma_g = 1;
+    pp.mfma_xcd_span = (p.mfma_xcd & 1u) && cnt % 8 == 0 && cnt / 8 <= 0xffffffffull ? (uint32_t)(cnt / 8) : 0u;
     // pp.mfma_g = tickets per wave; a workgroup of W waves hands out W times as many
     auto grid_for = [&](int waves) { return (cnt + (uint64_t)pp.mfma_g * waves - 1) / ((uint64_t)pp.mfma_g * waves); };
     switch (mfma_ksteps_for(p.stage[0].ntaps)) {

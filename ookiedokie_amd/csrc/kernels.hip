@@ -802,8 +802,12 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
         const int L = p.quiet_lsb;
         const bool loud = !(mx.x < L && mx.y < L && mn.x > -L && mn.y > -L);
         if (!p.fir_out && __ballot(loud) == 0) {
-            if (tid < G::F / 64) words[(J0 >> 6) + tid] = 0;
-            if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = 0;
+            // (sparse output: nothing is stored -- what the tile's words and info hold carries an older run's stamp
+            //  and reads as quiet, tile_live)
+            if (!p.sparse) {
+                if (tid < G::F / 64) words[(J0 >> 6) + tid] = 0;
+                if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = 0;
+            }
             if (p.quiet_count && tid == 0) atomicAdd(p.quiet_count + (blockIdx.x % kQuietCounters), 1u);
             return;
         }
@@ -1315,7 +1319,9 @@ hipError_t launch_front(const FrontParams &p, uint32_t num_captures, bool exact,
 }
 
 bool front_sparse_capable(const FrontParams &p) {
-    return use_fir1(p) && p.quiet_lsb > 0 && !p.fir_out;
+    // (round 3: the two-stage kernels too -- their quiet tiles stored 36 bytes each, 150 MB of small stores per
+    //  16 GiB capture beside the read stream: the backend default filter ran 15 % behind the 1-stage one for it)
+    return (use_fir1(p) || use_fir2(p)) && p.quiet_lsb > 0 && !p.fir_out;
 }
 
 bool front_streams(const FrontParams &p) {
@@ -1371,7 +1377,7 @@ hipError_t launch_front_stream(const FrontParams &p, StreamCtl ctl, bool exact, 
 // ---------------------------------------------------------------------------
 // sparse front-end output: making the bit words dense again
 // ---------------------------------------------------------------------------
-// With FrontParams::sparse the tuned 1-stage kernels store nothing for quiet
+// With FrontParams::sparse the tuned kernels (1 stage; 2 x decimate-by-2) store nothing for quiet
 // tiles, and what an earlier run left there is told apart by the run stamp in
 // the tile info (tile_live): no pass over the tiles between runs (round 2 first
 // zeroed the previous run's tiles before every run: 60 us and 107 MB of

@@ -74,6 +74,8 @@ struct FrontParams {
                                 // in ACCUMULATOR units (power / mfma_c^2: mfma_scale_band)
     float p_lo_w, p_hi_w;       // ... of a tile with samples beyond (two sample pieces)
     uint32_t mfma_g;            // wave tiles (tickets) per wave of a workgroup (the A-fragment image is fetched once for them)
+    uint32_t mfma_xcd;          // bit 0 / 1: the 1-stage / decimate-by-4 launches give every XCD one contiguous run of tiles
+    uint32_t mfma_xcd_span;     // (set by the launchers: tiles per XCD of this launch, 0 = positions are tiles)
     uint64_t tile_end;          // first wave tile past this launch (set by launch_front_mfma)
     uint32_t mfma_debug;        // experiments (OOKD_MFMA_DEBUG): bit 0 = every tile takes the quiet exit (timing only)
 };

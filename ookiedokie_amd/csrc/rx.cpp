@@ -332,6 +332,7 @@ struct ookd_rx {
     DevBuf<uint16_t> d_mfma_a;
     float mfma_c = 0, p_lo_n = 0, p_hi_n = 0, p_lo_w = 0, p_hi_w = 0;
     uint32_t mfma_g = 0;
+    uint32_t mfma_xcd = 2;          // FrontParams::mfma_xcd (OOKD_MFMA_XCD)
     int quiet_lsb = 0;              // 0 = the quiet shortcut never applies
     bool exact = false;
     bool count_quiet = false;
@@ -572,6 +573,7 @@ struct ookd_rx {
         p.p_lo_w = p_lo_w;
         p.p_hi_w = p_hi_w;
         p.mfma_g = mfma_g;
+        p.mfma_xcd = mfma_xcd;
         {
             static const uint32_t dbg = dev_getenv("OOKD_MFMA_DEBUG") ? (uint32_t)atoi(dev_getenv("OOKD_MFMA_DEBUG")) : 0u;
             p.mfma_debug = dbg;
@@ -1598,6 +1600,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             // fetch a 20 / 36 KB image each (config2 sweep: 474 / 545 / 599 / 623 / 635 Gsamples/s at 2 / 4 / 8 / 16 / 32)
             rx->mfma_g = mt.ksteps <= 6 ? 4u : mt.ksteps <= 10 ? 16u : 32u;
             if (const char *g = dev_getenv("OOKD_MFMA_G")) rx->mfma_g = (uint32_t)std::min(4096, std::max(1, atoi(g)));
+            if (const char *x = dev_getenv("OOKD_MFMA_XCD")) rx->mfma_xcd = (uint32_t)atoi(x);
         }
     }
     if (filter && cfg->threshold > 0.0f && std::isfinite(cfg->threshold) && !(cfg->flags & OOKD_RX_NO_QUIET_SKIP)) {
