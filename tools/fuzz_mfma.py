@@ -23,9 +23,11 @@ import ookiedokie_amd as ok          # noqa: E402
 import oracle as O                   # noqa: E402  (checker)
 
 
-def random_taps(rng):
+def random_taps(rng, nmax=256):
     n = int(rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256,
                         int(rng.integers(1, 257))]))
+    if nmax < 256:
+        n = int(rng.choice([1, 2, nmax - 1, nmax, int(rng.integers(1, nmax + 1))]))
     kind = int(rng.integers(0, 5))
     if kind == 0:
         k = np.arange(n) - (n - 1) / 2.0
@@ -89,12 +91,24 @@ def main():
                  mismatches=[])
     t_end = time.time() + args.seconds
     while time.time() < t_end:
-        taps = random_taps(rng)
+        # one stage without decimation, or (a third of the cases) the backend default's shape: two decimate-by-2
+        # stages of up to 16 and 32 taps, folded into one decimate-by-4 product on the matrix cores
+        two = rng.random() < 0.33
+        if two:
+            t1, t2 = random_taps(rng, 16), random_taps(rng, 32)
+            stages = [{"decimation": 2, "taps": [float(t) for t in t1]}, {"decimation": 2, "taps": [float(t) for t in t2]}]
+            taps = np.array([np.abs(t1.astype(np.float64)).sum() * np.abs(t2.astype(np.float64)).sum()], dtype=np.float64)
+            stats["two_stage_cases"] = stats.get("two_stage_cases", 0) + 1
+        else:
+            taps = random_taps(rng)
+            stages = [{"decimation": 1, "taps": [float(t) for t in taps]}]
         n = int(rng.integers(2000, 120000 if taps.size > 64 else 400000))
+        if two:
+            n -= n % 4
         iq = random_capture(rng, n)
         path = os.path.join(tmp, "f.json")
         with open(path, "w") as f:
-            json.dump({"filter": {"stages": [{"decimation": 1, "taps": [float(t) for t in taps]}]}}, f)
+            json.dump({"filter": {"stages": stages}}, f)
         flt = ok.Filter.load(path)
         of = O.load_filter_json(path)
         spb = int(rng.choice([512, 4096, 8192]))
@@ -128,7 +142,7 @@ def main():
                 if not valu and not keep:
                     stats["recomputes"] += int(got.stats["guard_recomputes"])
                 if not (okb and okf):
-                    stats["mismatches"].append(dict(ntaps=int(taps.size), n=n, thr=thr, valu=valu, keep=keep, bits_ok=okb,
+                    stats["mismatches"].append(dict(ntaps=int(taps.size), two_stage=bool(two), n=n, thr=thr, valu=valu, keep=keep, bits_ok=okb,
                                                     floats_ok=okf, seed=args.seed, case=stats["cases"],
                                                     first_diff=int(np.nonzero(bits != want.bits)[0][0]) if not okb and bits.size == want.bits.size else -1))
                 rx.close()
