@@ -4,7 +4,8 @@ import csv
 import glob
 import sys
 
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)     # (the newest: gpurun merges runs)
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'].split('(')[0].replace('void ookd::', '').replace('ookd::', '') for r in rows]
