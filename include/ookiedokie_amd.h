@@ -184,14 +184,15 @@ enum {
      * Set this for the packed-VALU loop instead (exists so the tests run both). */
     OOKD_RX_FIR_VALU = 1u << 8,
     /* State machine scan: always compose the per-block transition tables.  By
-     * default the scan first looks for SYNCHRONISING spans -- stretches of
-     * constant level long enough that the machine ends them in one state
-     * whatever state it entered them in without an error (the silence between
-     * two messages) --, walks from each to the next taking that state for
-     * granted, and checks every such assumption with the walk that arrives
-     * there; the composing kernels only run for a capture where a check fails
-     * or no such span turns up within 512 edges.  Identical results; the flag
-     * exists so the tests can run both (stats.scan_entry_form). */
+     * default a long edge list (200 000 edges and more) is first searched for
+     * SYNCHRONISING spans -- stretches of constant level long enough that the
+     * machine can only end them in one of a few states whatever state it
+     * entered them in (the silence between two messages) --, every stretch
+     * between two of them is walked once per such state, and a scan over the
+     * resulting few-entry maps picks the true one; the composing kernels run
+     * for short edge lists and for captures without such spans (no one within
+     * 512 edges).  Identical results; the flag exists so the tests can run
+     * both (stats.scan_entry_form). */
     OOKD_RX_SCAN_TABLES = 1u << 9
 };
 

@@ -2585,11 +2585,11 @@ __device__ __forceinline__ uint32_t sync_map_then(uint32_t a, uint32_t b) {
     for (uint32_t x = 0; x < kSyncK; ++x) r |= sync_map_apply(b, sync_map_apply(a, x) & 3u) << (8u * x);
     return r;
 }
-// blocks per thread of scan_syncpick_kernel, at most (1024 threads: captures up to 1.5 M edges; beyond, the
-// composing kernels).  The digests of a capture's blocks go through the LDS: fetched and stored in order, coalesced
+// blocks per thread of scan_syncpick_kernel, at most (1024 threads: captures up to 2.1 M edges -- a 32 GiB shard of
+// the bench capture has 1.5 M; beyond, the composing kernels).  The digests of a capture's blocks go through the LDS: fetched and stored in order, coalesced
 // (a thread reading its own run of 32-byte records from memory touched a cache line per lane and word: 73 000 line
 // requests from one CU, 32 us), read and rewritten there by the thread that owns the run.
-constexpr uint32_t kPickPer = 24;
+constexpr uint32_t kPickPer = 32;
 
 __device__ __forceinline__ uint32_t sync_dig_map(uint32_t dig) {
     const uint32_t mb = dig >> kSyncDigMap;
@@ -2729,18 +2729,22 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 // through the LDS, no barrier -- every lane asks for its leaf's code and its two edges at once.
                 if (l < count) {
                     const uint64_t i = first + l;
-                    // (the walk from synchronising spans keeps a plane per candidate: scan_syncpick_kernel says which)
-                    size_t plane = 0;
-                    if (sync_form) {
-                        const uint32_t se = sp.sync_sel[w];
-                        plane = (size_t)((l < (se & 0x7fu) ? se >> 8 : se >> 12) & 3u) * sp.pre_plane;
-                    }
-                    uint32_t in = sp.pre_codes[plane + (size_t)w * LB + l];
-                    if (sync_form) {            // state | bit count << 7 (scan_syncwalk_kernel)
-                        const uint32_t pc = in & 0x7fu, pn = in >> 7;
-                        in = pc < T.S ? pc * T.NB1 + pn : (pc == T.S ? T.S * T.NB1 + pn : pn);
-                    }
+                    const size_t at = (size_t)w * LB + l;
                     const uint64_t e_before = edges[i - 1], e_at = edges[i];
+                    uint32_t in;
+                    if (sync_form) {
+                        // the walk from synchronising spans keeps a plane per candidate and scan_syncpick_kernel says
+                        // which: all four asked for together with the selection (one round trip, not two)
+                        const uint32_t se = sp.sync_sel[w];
+                        const uint32_t c0 = sp.pre_codes[at], c1 = sp.pre_codes[at + sp.pre_plane];
+                        const uint32_t c2 = sp.pre_codes[at + 2 * sp.pre_plane], c3 = sp.pre_codes[at + 3 * sp.pre_plane];
+                        const uint32_t pl = (l < (se & 0x7fu) ? se >> 8 : se >> 12) & 3u;
+                        in = pl == 0 ? c0 : pl == 1 ? c1 : pl == 2 ? c2 : c3;
+                        const uint32_t pc = in & 0x7fu, pn = in >> 7;       // state | bit count << 7 (scan_syncwalk_kernel)
+                        in = pc < T.S ? pc * T.NB1 + pn : (pc == T.S ? T.S * T.NB1 + pn : pn);
+                    } else {
+                        in = sp.pre_codes[at];
+                    }
                     PSim f;
                     Acc a;
                     bool alive = true;
