@@ -184,7 +184,7 @@ enum {
      * Set this for the packed-VALU loop instead (exists so the tests run both). */
     OOKD_RX_FIR_VALU = 1u << 8,
     /* State machine scan: always compose the per-block transition tables.  By
-     * default a long edge list (200 000 edges and more) is first searched for
+     * default an edge list of 20 000 edges and more is first searched for
      * SYNCHRONISING spans -- stretches of constant level long enough that the
      * machine can only end them in one of a few states whatever state it
      * entered them in (the silence between two messages) --, every stretch

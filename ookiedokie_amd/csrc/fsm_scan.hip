@@ -2675,10 +2675,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams 
         lastc[tid] = last;
         __syncthreads();
         uint32_t before = 0;
-        for (uint32_t t = tid; t-- > 0;) {
-            if (lastc[t] != 0xffffffffu) {
-                before = lastc[t];
-                break;
+        if (b0 < b1) {                          // (a thread without blocks has nothing to look for: with 720 blocks for
+                                                //  1024 threads the idle ones went back over 300 entries -- 15 us)
+            for (uint32_t t = tid; t-- > 0;) {
+                if (lastc[t] != 0xffffffffu) {
+                    before = lastc[t];
+                    break;
+                }
             }
         }
         for (uint32_t b = b0; b < b1; ++b) {

@@ -380,7 +380,7 @@ struct ookd_rx {
     // decides (a stream of captures of one kind settles in one form or the other).
     static constexpr uint32_t kSyncBackoff = 8;
     uint32_t sync_backoff = 0;              // runs left in the composing form
-    uint64_t sync_min_edges = 200000;       // edge lists expected shorter than this are composed (OOKD_SYNC_MIN_EDGES: tests)
+    uint64_t sync_min_edges = 20000;        // edge lists expected shorter than this are composed (OOKD_SYNC_MIN_EDGES: tests)
     uint32_t sync_mode = 0;                 // of the scan in flight: FsmScanArgs::sync_try
     std::vector<uint64_t> mixed_errs;       // error positions of a run whose refused captures were redone (host side)
     bool mixed_valid = false;
@@ -657,9 +657,10 @@ struct ookd_rx {
 
     uint32_t next_sync_mode() {
         if (!scan_sync) return sync_mode = 0;
-        // a short edge list goes through the composing kernels faster (their depth is what counts there: 152 against
-        // 160 us of chain for the 46 000 edges of a 1 GiB bench capture; 223 against 120 us for the 737 000 of 16 GiB):
-        // by the edge count of this context's last run -- before there is one, by the capture's length
+        // a short edge list goes through the composing kernels faster: the walk ends with its longest region (a few
+        // hundred leaves at 0.14 us, whatever the capture's size) -- chain 131 against 153 us for the 46 000 edges of a
+        // 1 GiB bench capture, 275 against 400 for the 737 000 of 16 GiB, about even at 20 000.  By the edge count of
+        // this context's last run; before there is one, by the capture's length
         const uint64_t expect = stats.num_edges ? stats.num_edges : ((uint64_t)run_n_out * run_caps) >> 12;
         if (expect < sync_min_edges) return sync_mode = 0;
         if (sync_backoff == 0) return sync_mode = 2;

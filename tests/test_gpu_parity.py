@@ -54,7 +54,7 @@ def _odev(oracle, name, rate=RATE):
 @contextlib.contextmanager
 def _sync_walk_forced(on=True):
     """Receivers created inside try the scan's walk from synchronising spans whatever the expected edge count
-    (by default an edge list under 200 000 goes through the composing kernels)."""
+    (by default an edge list under 20 000 goes through the composing kernels)."""
     keys = ("OOKD_DEVELOPER", "OOKD_SYNC_MIN_EDGES")
     old = {k: os.environ.get(k) for k in keys}
     if on:

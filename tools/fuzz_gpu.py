@@ -7,7 +7,7 @@ rates and buffer sizes.  Not part of the test suite (minutes); prints a JSON sum
     python tools/fuzz_gpu.py [--seconds 300] [--seed 1] [--sync-walk]
 
 --sync-walk: the scan's default legs find the entry states by the walk from synchronising spans whatever the edge
-count (by default only edge lists of 200 000 and more do), and one more leg runs the composing kernels
+count (by default only edge lists of 20 000 and more do), and one more leg runs the composing kernels
 (OOKD_RX_SCAN_TABLES); the summary counts which form each run ended in (scan_entry_form).
 """
 import argparse

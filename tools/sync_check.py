@@ -7,7 +7,7 @@ import os
 import sys
 
 os.environ["OOKD_DEVELOPER"] = "1"
-os.environ["OOKD_SYNC_MIN_EDGES"] = "0"      # the walk whatever the edge count (default: from 200 000 edges on)
+os.environ["OOKD_SYNC_MIN_EDGES"] = "0"      # the walk whatever the edge count (default: from 20 000 edges on)
 
 import torch
 
