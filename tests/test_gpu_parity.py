@@ -708,7 +708,8 @@ def test_devices_beyond_64_states_run_through_the_round_form(ok, oracle):
 
 # ------------------------------------------------------- batched / sharded ----
 
-def test_batched_captures_are_independent(ok, oracle, vectors):
+@pytest.mark.parametrize("walk", [False, True])
+def test_batched_captures_are_independent(ok, oracle, vectors, walk):
     import torch
     g, iq = _g1(vectors)
     n = 300000
@@ -726,7 +727,8 @@ def test_batched_captures_are_independent(ok, oracle, vectors):
     dev_t = torch.from_numpy(host).cuda()
     f = _flt(ok, "fs32_fs4")
     d = _dev(ok, "p3l-nexa2012")
-    rx = ok.Receiver(f, d, max_samples=n, max_captures=5)
+    with _sync_walk_forced(walk):          # (the scan's walk from synchronising spans: whatever the edge count)
+        rx = ok.Receiver(f, d, max_samples=n, max_captures=5)
     got = rx.rx_device(dev_t.data_ptr(), n, num_captures=5, stride=stride)
     of = _ofir(oracle, "fs32_fs4")
     od = _odev(oracle, "p3l-nexa2012")
@@ -741,7 +743,8 @@ def test_batched_captures_are_independent(ok, oracle, vectors):
     assert total == len(got.msg_samples)
 
 
-def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle):
+@pytest.mark.parametrize("walk", [False, True])
+def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle, walk):
     """Six independent captures in one call, each with stuck stretches (and the first edges of
     a capture right behind one): per capture the oracle's messages, all in the scan form."""
     import torch
@@ -756,7 +759,8 @@ def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle):
     dev_t = torch.from_numpy(host).cuda()
     d = _dev(ok, "p3l-nexa2012")
     od = _odev(oracle, "p3l-nexa2012")
-    rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
+    with _sync_walk_forced(walk):
+        rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
     got = rx.rx_device(dev_t.data_ptr(), n, num_captures=len(caps), stride=stride)
     assert got.stats["fsm_path"] == 1, got.stats["fsm_fallback_reason"]
     total = 0
@@ -771,7 +775,8 @@ def test_batched_captures_with_glitches_inside_bit_gaps(ok, oracle):
     rx.close()
 
 
-def test_batch_with_one_refused_capture_redoes_only_that_one(ok, oracle):
+@pytest.mark.parametrize("walk", [False, True])
+def test_batch_with_one_refused_capture_redoes_only_that_one(ok, oracle, walk):
     """A stretch of inert edges deeper than the scan's stuck codes hold (six short pulses inside ONE bit
     gap of p3l-nexa2012: twelve edges on which nothing fires) makes the scan refuse that capture.  In a
     batch the other captures keep the scan's results; the refused one is redone alone in the round form
@@ -818,7 +823,8 @@ def test_batch_with_one_refused_capture_redoes_only_that_one(ok, oracle):
     r1 = solo.rx(host[1, :2 * n])
     assert r1.stats["fsm_path"] == 3 and r1.stats["fsm_fallback_reason"] != 0
     solo.close()
-    rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
+    with _sync_walk_forced(walk):
+        rx = ok.Receiver(None, d, max_samples=n, max_captures=len(caps))
     for order in ((0, 1, 2, 3), (0, 2, 3)):                 # with the refused capture, then a clean batch on the same context
         sub = torch.from_numpy(host[list(order)].copy()).cuda()
         got = rx.rx_device(sub.data_ptr(), n, num_captures=len(order), stride=stride)
@@ -838,7 +844,7 @@ def test_batch_with_one_refused_capture_redoes_only_that_one(ok, oracle):
     rx.close()
 
 
-def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers):
+def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers, walk=False):
     """One capture cut into shards (as 8 GPUs would hold it): halo + carried
     FSM state reproduce the single-pass result."""
     import torch
@@ -858,7 +864,8 @@ def _check_sharded(ok, oracle, iq, filt, devname, shard_buffers):
     ins = [None] * nsh
     H = None
     for r in range(nsh):
-        rx = ok.Receiver(f, d, max_samples=shard, samples_per_buffer=spb)
+        with _sync_walk_forced(walk):      # (shards begun and refined through the scan's walk from synchronising spans)
+            rx = ok.Receiver(f, d, max_samples=shard, samples_per_buffer=spb)
         H = rx.halo_samples
         lo, hi = bounds[r], bounds[r + 1]
         halo = iq[2 * (lo - H):2 * lo] if r > 0 and H else None
@@ -899,11 +906,12 @@ def test_sharded_capture_equals_whole(ok, oracle, vectors, filt):
     assert _check_sharded(ok, oracle, iq, filt, "p3l-nexa2012", 40) == 3
 
 
-def test_sharded_capture_with_glitches_inside_bit_gaps(ok, oracle):
+@pytest.mark.parametrize("walk", [False, True])
+def test_sharded_capture_with_glitches_inside_bit_gaps(ok, oracle, walk):
     """Shard boundaries that fall into messages whose bit gaps hold glitch pulses: a shard
     may begin inside a stretch in which no trigger fires (carried counter != 0)."""
     iq = _iq_from_stream(stream_from_runs(_glitchy_message_runs("p3l-nexa2012", 24, seed=5)))
-    assert _check_sharded(ok, oracle, iq, None, "p3l-nexa2012", 7) >= 20
+    assert _check_sharded(ok, oracle, iq, None, "p3l-nexa2012", 7, walk=walk) >= 20
 
 
 # ------------------------------------------------------- fine-grained APIs ----
