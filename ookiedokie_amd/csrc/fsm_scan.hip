@@ -22,9 +22,16 @@
 //            compose them into one table per block;
 //   blocks : one workgroup per capture walks the block tables from the true
 //            start state;
-//   emit   : per block, walk the true path, then every edge re-simulates its
-//            own span from its now-known incoming state and records what
-//            happened (appended bits, resets, OUTPUT_READY, ERROR);
+//   entry  : the state every leaf is entered in, from the block tables;
+//   (sync  : or -- for edge lists long enough to pay for it -- without any
+//            tables: a leaf that ends in one of at most four states whatever
+//            it was entered in (the silence between two messages) splits the
+//            capture; every stretch between two of them is walked once per
+//            such state, and a scan over the few-entry maps picks the true
+//            one: scan_sync / scan_syncwalk / scan_syncpick, further down;)
+//   emit   : every edge re-simulates its own span from its now-known
+//            incoming state and records what happened (appended bits,
+//            resets, OUTPUT_READY, ERROR);
 //   finish : prefix sums over those records rebuild the payloads (bit t of a
 //            message is the t-th append since the last reset), the message
 //            list, the error list and the outgoing state.
