@@ -544,7 +544,10 @@ void fir1_mfma_kernel(const FrontParams p) {
                 for (int d = 16; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w32 & 1u));
                 const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(w32 >> 31), 31);
-                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+                // the word that holds the first change: lane n < 32 holds bits 32 n .. 32 n + 31 of the tile
+                const uint64_t chl = __ballot(hh == 0 && ch != 0);
+                const uint32_t widx = chl ? (uint32_t)__builtin_ctzll(chl) >> 1 : 0u;
+                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (widx << kTileWordShift) | (first << 30) | (last << 31) | p.stamp_bits;
             }
             const uint32_t up = (uint32_t)__shfl_xor((int)w32, 1);
             if (hh == 0 && (n & 1u) == 0) {
@@ -877,7 +880,10 @@ void fir2_mfma_kernel(const FrontParams p) {
                 for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w64 & 1ull));
                 const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w64 >> 63), 12);
-                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+                // the word that holds the first change: lanes 0, 4, 8, 12 hold the tile's words 0 .. 3
+                const uint64_t chl = __ballot((n & 3u) == 0 && g == 0 && ch != 0);
+                const uint32_t widx = chl ? (uint32_t)__builtin_ctzll(chl) >> 2 : 0u;
+                if (tid == 0) *uniform_ptr(tile_info + tile) = cnt | (widx << kTileWordShift) | (first << 30) | (last << 31) | p.stamp_bits;
             }
             if ((n & 3u) == 0 && g == 0) {
                 const gbytes_w wb = uniform_ptr((gbytes_w)(words + (M0 >> 6)));

@@ -317,7 +317,10 @@ __device__ __forceinline__ uint32_t fir1_tile_compute(const FrontParams &p, floa
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> (R - 1)) & 1u), 63);
-        info = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+        // the word that holds the first change: lane l holds bits R l .. R l + R - 1 of the tile
+        const uint64_t chl = __ballot(ch != 0);
+        const uint32_t widx = chl ? ((uint32_t)__builtin_ctzll(chl) * (uint32_t)R) >> 6 : 0u;
+        info = cnt | (widx << kTileWordShift) | (first << 30) | (last << 31) | p.stamp_bits;
     }
 
     // 64 / R lanes x R bits -> one 64-bit word
@@ -893,7 +896,9 @@ __global__ __launch_bounds__(64 * kFir2Waves) void fir2_bits_kernel(const FrontP
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nib & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((nib >> (G::R2 - 1)) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+        const uint64_t chl = __ballot(ch != 0);         // (the word that holds the first change: R2 bits per lane)
+        const uint32_t widx = chl ? ((uint32_t)__builtin_ctzll(chl) * (uint32_t)G::R2) >> 6 : 0u;
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + J0 / G::F] = cnt | (widx << kTileWordShift) | (first << 30) | (last << 31) | p.stamp_bits;
     }
     uint32_t half = nib << (4u * (tid & 7u));
     half |= __shfl_xor(half, 1);
@@ -1058,7 +1063,9 @@ __global__ __launch_bounds__(64) void nofir_bits_kernel(const FrontParams p) {
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(mask & 1u));
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)((mask >> 15) & 1u), 63);
-        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (first << 30) | (last << 31) | p.stamp_bits;
+        const uint64_t chl = __ballot(ch != 0);         // (the word that holds the first change: 16 bits per lane)
+        const uint32_t widx = chl ? (uint32_t)__builtin_ctzll(chl) >> 2 : 0u;
+        if (tid == 0) p.tile_info[(uint64_t)cap * p.tiles_per_cap + (t0 >> 10)] = cnt | (widx << kTileWordShift) | (first << 30) | (last << 31) | p.stamp_bits;
     }
     const uint32_t pair = mask | (__shfl_xor(mask, 1) << 16);      // valid on even lanes
     const uint32_t hi = __shfl_xor(pair, 2);

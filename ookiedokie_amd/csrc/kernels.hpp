@@ -80,14 +80,17 @@ struct FrontParams {
     uint32_t mfma_debug;        // experiments (OOKD_MFMA_DEBUG): bit 0 = every tile takes the quiet exit (timing only)
 };
 
-// A tile info word:  level changes inside the tile (10 bits: tiles hold at most 1024 outputs)
-// | run stamp << 10 (20 bits) | first bit << 30 | last bit << 31.  Words and info of a tile are only
-// meaningful when the info carries the current run's stamp; anything else -- never written, or
-// left by an earlier run (sparse output) -- is a quiet tile: all bits zero.
-constexpr uint32_t kTileStampShift = 10;
-constexpr uint32_t kTileStampMask = 0x3ffffc00u;
-constexpr uint32_t kTileStampMax = 0xfffffu;
-// -> count | first << 30 | last << 31 of a live tile, 0 of a quiet / stale one
+// A tile info word:  level changes inside the tile (10 bits: tiles hold at most 1024 outputs; the change between the
+// tile's first bit and the tile before is NOT in it) | which of the tile's 64-bit words holds the first of them
+// << 10 (4 bits; round 3: edge_write reads that one word of a tile with one change, not the tile) | run stamp << 14
+// (16 bits) | first bit << 30 | last bit << 31.  Words and info of a tile are only meaningful when the info carries
+// the current run's stamp; anything else -- never written, or left by an earlier run (sparse output) -- is a quiet
+// tile: all bits zero.
+constexpr uint32_t kTileWordShift = 10;
+constexpr uint32_t kTileStampShift = 14;
+constexpr uint32_t kTileStampMask = 0x3fffc000u;
+constexpr uint32_t kTileStampMax = 0xffffu;
+// -> count | first word << 10 | first << 30 | last << 31 of a live tile, 0 of a quiet / stale one
 __host__ __device__ __forceinline__ uint32_t tile_live(uint32_t info, uint32_t stamp_bits) {
     return ((info ^ stamp_bits) & kTileStampMask) ? 0u : (info & ~kTileStampMask);
 }

@@ -687,7 +687,7 @@ struct ookd_rx {
 // A new run of the front end: the next stamp.  Sparse output leaves the quiet tiles' words and infos
 // alone -- whatever they hold carries an older stamp and reads as quiet -- so nothing is zeroed between
 // runs, except when the geometry changes (rare; keeps "a zero info means zero words" simple to reason
-// about) or the 20-bit stamp wraps (every 2^20 - 1 runs): then every tile the buffer may hold is zeroed.
+// about) or the 16-bit stamp wraps (every 2^16 - 1 runs): then every tile the buffer may hold is zeroed.
 int ookd_rx::prepare_front(FrontParams &fp) {
     const uint32_t tile_bits = front_tile_bits(fp);
     if (!tile_bits) return OOKD_OK;

@@ -1132,7 +1132,7 @@ def test_context_is_reusable_across_sizes(ok, oracle, vectors):
 @pytest.mark.parametrize("filt", ["fs32_fs4", "fs128_fs16_dec4"])
 @pytest.mark.parametrize("chunk,stream_form,read_bits,stamp0", [(0, False, True, None), (32768, False, True, None), (0, True, True, None),
                                                                 (0, False, False, None), (32768, False, False, None),
-                                                                (0, False, False, 0xfffff - 3), (0, False, True, 0xfffff - 2)])
+                                                                (0, False, False, 0xffff - 3), (0, False, True, 0xffff - 2)])
 def test_sparse_bit_words_do_not_leak_between_runs(ok, oracle, vectors, chunk, stream_form, read_bits, stamp0, filt, monkeypatch):
     """The tuned front ends (1 stage; the two decimate-by-2 stages of the backend default) store nothing for quiet tiles: what earlier runs left in their words
     and tile infos carries those runs' stamps and must read as quiet (kernels.hpp: tile_live), for the
@@ -1140,7 +1140,7 @@ def test_sparse_bit_words_do_not_leak_between_runs(ok, oracle, vectors, chunk, s
     raw words.  Different captures of equal and of different lengths through one context, whole and
     pipelined in chunks, hardware-dispatched and streaming front end, with the words read back after
     every run (which cleans up) and never (stale tiles of many runs pile up), and across the wrap of the
-    20-bit stamp: bits, edges and messages of every run must be the oracle's."""
+    16-bit stamp: bits, edges and messages of every run must be the oracle's."""
     if stream_form:
         monkeypatch.setenv("OOKD_DEVELOPER", "1")
         monkeypatch.setenv("OOKD_FRONT_STREAM", "1")
