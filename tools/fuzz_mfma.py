@@ -90,7 +90,11 @@ def main():
     stats = dict(cases=0, receivers=0, samples=0, recomputes=0, mfma_cases=0, valu_only_cases=0, max_err_over_scale=0.0,
                  mismatches=[])
     t_end = time.time() + args.seconds
+    last = time.time()
     while time.time() < t_end:
+        if time.time() - last > 30:         # (a run that stays silent for minutes is taken to be hung)
+            last = time.time()
+            print("[fuzz_mfma] %d cases, %d mismatches" % (stats["cases"], len(stats["mismatches"])), file=sys.stderr, flush=True)
         # one stage without decimation, or (a third of the cases) the backend default's shape: two decimate-by-2
         # stages of up to 16 and 32 taps, folded into one decimate-by-4 product on the matrix cores
         two = rng.random() < 0.33
