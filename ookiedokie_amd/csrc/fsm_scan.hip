@@ -2265,6 +2265,10 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(ScanParams sp) {
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t nbp0 = g_mr[0], sync_off = g_mr[3];
+    // (one capture -- the usual run: its extent once, not a dependent round trip per block)
+    const bool one = sp.f.num_captures == 1;
+    uint64_t e0_one = 0;
+    const uint64_t ne_one = one ? cap_edges(sp.f, 0, e0_one) : 0;
     for (uint32_t gb = blockIdx.x * 4u + wave; gb < total + sp.f.num_captures; gb += gridDim.x * 4u) {
         if (gb >= total) {
             // one extra item per capture: its first span from the concrete incoming state
@@ -2279,10 +2283,12 @@ __global__ __launch_bounds__(256) void scan_sync_kernel(ScanParams sp) {
             }
             continue;
         }
-        uint32_t cap, lb;
-        locate_block(sp, gb, cap, lb);
-        uint64_t e0;
-        const uint64_t ne = cap_edges(sp.f, cap, e0);
+        uint32_t cap = 0, lb = gb;
+        uint64_t e0 = e0_one, ne = ne_one;
+        if (!one) {
+            locate_block(sp, gb, cap, lb);
+            ne = cap_edges(sp.f, cap, e0);
+        }
         const uint64_t *edges = sp.f.edges + e0;
         const uint64_t first = 1 + (uint64_t)lb * LB;
         const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
