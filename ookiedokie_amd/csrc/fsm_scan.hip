@@ -573,6 +573,7 @@ constexpr uint32_t kPkSensitive = 0x40000000u;
 constexpr uint32_t kPkRelative = 0x20000000u;   // [7:0] end state, [23:8] appended bits
 constexpr uint32_t kPkShared = 0x10000000u;     // transient: class "all bits" takes this result too
 constexpr uint32_t kPkStuck = 0x08000000u;      // no trigger fired on the edge, the counter runs on
+constexpr uint32_t kPkEventShift = 24;          // relative results: bits 24..25 = the span's events in short (pack_normal)
 
 __host__ __device__ __forceinline__ uint32_t pack_absolute(uint32_t code, uint32_t NB1) {
     return code | ((code / NB1) << 16) | kPkAbsolute;
@@ -598,6 +599,11 @@ __host__ __device__ __forceinline__ uint32_t pack_normal(const LTab &T, const PS
         const uint32_t nbo = out - ocur * NB1;
         const uint32_t delta = nbo >= nb0 ? nbo - nb0 : 0u;
         packed = ocur | (delta << 8) | kPkRelative;         // relative: nb + delta (saturating)
+        // what the span leaves behind for scan_emit_kernel, when that is all of it: nothing, or ONE appended bit
+        // (no output, no error, no reset -- and, the row not being bit-count sensitive, the same for every bit count
+        // of the class): bits 24..25 = 1 nothing, 2 / 3 a 0 / 1 appended; 0 = simulate
+        if (a.nout == 0 && a.nerr == 0 && !a.overflow && a.napp <= 1u)
+            packed |= (a.napp == 0 ? 1u : 2u + (a.appvals & 1u)) << kPkEventShift;
     }
     // no dependence on the bit count at all: class "all bits" takes the "few bits" result
     if (cls == 0 && !a.msgc_seen && !a.overflow) packed |= kPkShared;
@@ -2709,17 +2715,72 @@ __global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams 
 }
 
 // leaves of capture c live at events[e0 + c + i], i = 0 .. ne  (ne + 1 leaves)
+
+// regular leaf i of capture `cap`, entered in code `in`: simulate the span, record what happened
+__device__ __forceinline__ void emit_simulate(const ScanParams &sp, const LTab &T, uint32_t cap, const uint64_t *edges,
+                                              LeafEvDev *events, uint64_t i, uint32_t in) {
+    const uint64_t e_before = edges[i - 1], e_at = edges[i];
+    PSim f;
+    Acc a;
+    bool alive = true;
+    if (in == code_poison(T)) {
+        scan_refuse(sp, cap, (uint32_t)kFbPoison);
+        acc_init(a);
+        f.cur = f.nbits = f.k = f.prev = 0;
+    } else {
+        Span span;
+        span.pos0 = e_before + 1;
+        span.n = e_at - e_before - 1;
+        span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
+        span.has_edge = true;
+        span.prefix = 0;
+        if (in >= T.S * T.NB1 + 3) {            // entered stuck: from where the state was normal (span_entered)
+            uint32_t d, src;
+            stuck_decode(T, in, d, src);
+            span.prefix = e_before - edges[i - d - 1];
+            in = src;
+        }
+        alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
+        if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
+    }
+    write_event(events[i], a, f, alive);
+}
+
+// leaves a workgroup of scan_emit_kernel puts aside to simulate together at its end (sync form)
+constexpr uint32_t kEmitQueue = 1024;
+struct EmitQ {
+    uint32_t cap, in;
+    uint64_t i;
+};
+
 __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     __builtin_amdgcn_s_setprio(3);      // latency chain: issue ahead of a front-end kernel sharing the CU
     __shared__ LTab T;
+    __shared__ EmitQ s_q[kEmitQueue];
+    __shared__ uint32_t s_qn;
     copy_ltab(T, sp.ltab);
     __syncthreads();
-    if (threadIdx.x == 0) T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
+    if (threadIdx.x == 0) {
+        T.lvl0 = sp.has_prev ? fsm_level_at(sp.f, 0, -1) : 0u;
+        s_qn = 0;
+    }
     __syncthreads();
     if (*sp.fallback) return;
     const bool sync_form = sp.sync_try && !(*sp.sync_fail & 1u);
     const uint32_t LB = sp.leaf_block;
     const uint32_t total = sp.cap_block_off[sp.f.num_captures];
+    // Sync form: most leaves need no simulation.  The walk's copy of the rows (append_sync_codes) says per (state,
+    // class) and length interval what the span leaves behind when that is nothing or one appended bit -- a pulse, a
+    // bit gap: all but the leaves at a message's ends --, and scan_sync_kernel left every leaf's row offset: the rows
+    // into LDS (g_mr, from its start: 1 200 words for the shipped devices), one read per leaf.  The few that are left
+    // (2.6 % on the bench capture) are put aside and simulated TOGETHER at the workgroup's end: one or two of them in
+    // every wave cost every wave the latency of a whole simulation (44 us, as much as simulating all of them).
+    if (sync_form) {
+        const uint32_t r2 = sp.lt_merged[3] + 2u * (sp.lt_merged[0] + sp.lt_merged[1]);
+        const uint32_t n2 = (sp.lt_merged[0] + sp.lt_merged[1]) * 2u * T.S;
+        for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) g_mr[i] = sp.lt_merged[r2 + i];
+        __syncthreads();
+    }
     // work items: groups of FOUR blocks, then one "ends" item per capture (first span + tail).
     // A workgroup takes four blocks = 256 leaves, one per lane: waves 0 / 1 the even / odd leaves of blocks 0 and 1,
     // waves 2 / 3 those of blocks 2 and 3 -- leaves of one parity run at one level, so a wave's lanes sit in the
@@ -2730,8 +2791,10 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
     for (uint32_t wq = blockIdx.x; wq < nquad + sp.f.num_captures; wq += gridDim.x) {
         if (wq < nquad) {
             const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-            const uint32_t w = 4u * wq + 2u * (wave >> 1) + (lane >> 5);
-            const uint32_t l = 2u * (lane & 31u) + (wave & 1u);
+            // sync form: a wave takes a block, lane = leaf -- few leaves are simulated at all (below), and a wave's
+            // 64 records are 3 KB in a row; composing form: leaves of one parity (one level) per wave
+            const uint32_t w = sync_form ? 4u * wq + wave : 4u * wq + 2u * (wave >> 1) + (lane >> 5);
+            const uint32_t l = sync_form ? lane : 2u * (lane & 31u) + (wave & 1u);
             if (w < total) {
                 uint32_t cap, lb;
                 locate_block(sp, w, cap, lb);
@@ -2746,45 +2809,47 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 if (l < count) {
                     const uint64_t i = first + l;
                     const size_t at = (size_t)w * LB + l;
-                    const uint64_t e_before = edges[i - 1], e_at = edges[i];
-                    uint32_t in;
+                    uint32_t in, kind = 0, to = 0;
                     if (sync_form) {
                         // the walk from synchronising spans keeps a plane per candidate and scan_syncpick_kernel says
                         // which: all four asked for together with the selection (one round trip, not two)
                         const uint32_t se = sp.sync_sel[w];
                         const uint32_t c0 = sp.pre_codes[at], c1 = sp.pre_codes[at + sp.pre_plane];
                         const uint32_t c2 = sp.pre_codes[at + 2 * sp.pre_plane], c3 = sp.pre_codes[at + 3 * sp.pre_plane];
+                        const uint32_t rz = sp.rowz[at];
                         const uint32_t pl = (l < (se & 0x7fu) ? se >> 8 : se >> 12) & 3u;
                         in = pl == 0 ? c0 : pl == 1 ? c1 : pl == 2 ? c2 : c3;
                         const uint32_t pc = in & 0x7fu, pn = in >> 7;       // state | bit count << 7 (scan_syncwalk_kernel)
                         in = pc < T.S ? pc * T.NB1 + pn : (pc == T.S ? T.S * T.NB1 + pn : pn);
+                        if (pc < T.S && rz != kSyncNone) {
+                            const uint32_t q = g_mr[rz + 2u * pc + (pn >= T.max_bits ? 1u : 0u)];
+                            kind = (int32_t)q < 0 ? (q >> 24) & 3u : 0u;
+                            to = q & 0xffu;
+                        }
                     } else {
                         in = sp.pre_codes[at];
                     }
-                    PSim f;
-                    Acc a;
-                    bool alive = true;
-                    if (in == code_poison(T)) {
-                        scan_refuse(sp, cap, (uint32_t)kFbPoison);
+                    if (kind) {
+                        // nothing happened, or one bit was appended (the rows say which): no simulation
+                        PSim f;
+                        Acc a;
                         acc_init(a);
-                        f.cur = f.nbits = f.k = f.prev = 0;
+                        a.napp = kind >= 2u ? 1u : 0u;
+                        a.appvals = kind == 3u ? 1u : 0u;
+                        f.cur = to;
+                        f.nbits = f.k = 0;
+                        f.prev = ((uint32_t)(i & 1ull) ^ T.lvl0) ^ 1u;
+                        write_event(events[i], a, f, true);
                     } else {
-                        Span span;
-                        span.pos0 = e_before + 1;
-                        span.n = e_at - e_before - 1;
-                        span.L = (uint32_t)(i & 1ull) ^ T.lvl0;
-                        span.has_edge = true;
-                        span.prefix = 0;
-                        if (in >= T.S * T.NB1 + 3) {            // entered stuck: from where the state was normal (span_entered)
-                            uint32_t d, src;
-                            stuck_decode(T, in, d, src);
-                            span.prefix = e_before - edges[i - d - 1];
-                            in = src;
+                        const uint32_t slot = sync_form ? atomicAdd(&s_qn, 1u) : kEmitQueue;
+                        if (slot < kEmitQueue) {
+                            s_q[slot].cap = cap;
+                            s_q[slot].in = in;
+                            s_q[slot].i = i;
+                        } else {
+                            emit_simulate(sp, T, cap, edges, events, i, in);
                         }
-                        alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
-                        if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                     }
-                    write_event(events[i], a, f, alive);
                 }
             }
         } else {
@@ -2844,6 +2909,15 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             }
             __syncthreads();
         }
+    }
+    // the leaves put aside: simulated together
+    __syncthreads();
+    const uint32_t nq = min(s_qn, kEmitQueue);
+    for (uint32_t j = threadIdx.x; j < nq; j += blockDim.x) {
+        const EmitQ e = s_q[j];
+        uint64_t e0;
+        (void)cap_edges(sp.f, e.cap, e0);
+        emit_simulate(sp, T, e.cap, sp.f.edges + e0, sp.events + e0 + e.cap, e.i, e.in);
     }
 }
 
@@ -3644,8 +3718,9 @@ void append_sync_codes(std::vector<uint32_t> &merged, uint32_t S, uint32_t NB1, 
         }
     }
     // ... and the rows once more in the form the walk steps through (a state is kept as state / bit count, skip and
-    // poison as state S with bit count 0 / 1 / 2): state' | (bit count or bits appended) << 8 | relative << 30 |
-    // 0x80000000; 0 = not a plain result (stuck, bit-count sensitive, position dependent): the full step
+    // poison as state S with bit count 0 / 1 / 2): state' | (bit count or bits appended) << 8 | the span's events in
+    // short << 24 (pack_normal: what scan_emit_kernel writes without simulating) | relative << 30 | 0x80000000;
+    // 0 = not a plain result (stuck, bit-count sensitive, position dependent): the full step
     std::vector<uint32_t> rows2;
     for (size_t i = rows0; i < merged.size(); ++i) {
         const uint32_t p = merged[i];
@@ -3656,7 +3731,7 @@ void append_sync_codes(std::vector<uint32_t> &merged, uint32_t S, uint32_t NB1, 
             if (code < SNB + 3) q = cur | (nb << 8) | 0x80000000u;
         } else if (p & kPkRelative) {
             const uint32_t add = (p >> 8) & 0xffffu;
-            q = (p & 0xffu) | ((add > NB1 ? NB1 : add) << 8) | 0x40000000u | 0x80000000u;
+            q = (p & 0xffu) | ((add > NB1 ? NB1 : add) << 8) | (((p >> kPkEventShift) & 3u) << 24) | 0x40000000u | 0x80000000u;
         }
         rows2.push_back(q);
     }
