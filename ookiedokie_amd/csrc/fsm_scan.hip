@@ -533,6 +533,8 @@ struct ScanParams {
     uint16_t *cap_end;          // [captures] state after the last regular leaf
     uint16_t *cap_first;        // [captures] state after the first span (leaf kernel -> walk kernel)
     // entry codes from synchronising spans (scan_sync_kernel / scan_syncwalk_kernel / scan_syncpick_kernel)
+    uint32_t *ev_hot;           // [edges + captures] a leaf's record in one word (put_event); the 48-byte record only for
+                                // the leaves that need it
     uint32_t *sync_rec;         // [blocks][kSyncRecWords]: see kSyncRec*
     uint32_t *sync_dig;         // [blocks] what scan_syncpick_kernel needs of a record, in one word (kSyncDig*)
     uint32_t *sync_sel;         // [blocks] split | plane of the leaves below it << 8 | plane of the others << 12
@@ -1019,6 +1021,39 @@ __device__ __forceinline__ void write_event(LeafEvDev &ev, const Acc &a, const P
     ev.out_pos[0] = a.out_pos0;
     ev.out_pos[1] = a.out_pos1;
     ev.err_pos = a.err_pos;
+}
+
+// A leaf's record.  Nearly every span leaves nothing behind, or a few appended bits: ONE word per leaf says so -- appends
+// (8 bits) | 0x400: the 48-byte record holds the rest | passed through reset << 11 | appends before its last reset
+// << 16 | the first eight appended bits << 24 -- and only a leaf with an output, an error, more than eight appends, a
+// skipped rest-of-buffer at its end, or the capture's tail (whose end state goes out) gets the 48-byte record too.
+// (Round 2 stored and read the 48 bytes of every leaf: 35 MB each way per 16 GiB capture.)
+constexpr uint32_t kEvFull = 0x400u;
+__device__ __forceinline__ void put_event(const ScanParams &sp, size_t at, const Acc &a, const PSim &f, bool alive, bool tail) {
+    const uint32_t napp = a.napp > 255u ? 255u : a.napp;
+    const bool full = tail || !alive || a.nout != 0 || a.nerr != 0 || napp > 8u;
+    sp.ev_hot[at] = napp | (full ? kEvFull : 0u) | (a.reset_seen ? 0x800u : 0u) | ((a.apps_at_reset & 0xffu) << 16) |
+                    ((a.appvals & 0xffu) << 24);
+    if (full) write_event(sp.events[at], a, f, alive);
+}
+
+// ... and back (fin_block_scan)
+__device__ __forceinline__ LeafEvDev get_event(const ScanParams &sp, size_t at) {
+    const uint32_t hot = sp.ev_hot[at];
+    if (hot & kEvFull) return sp.events[at];
+    LeafEvDev ev;
+    ev.napp = (uint8_t)(hot & 0xffu);
+    ev.nout = ev.nerr = 0;
+    ev.flags = (uint8_t)((hot >> 11) & 1u);
+    ev.apps_at_reset = (uint8_t)((hot >> 16) & 0xffu);
+    ev.out_ab[0] = ev.out_ab[1] = 0;
+    ev.out_rb[0] = ev.out_rb[1] = 0xffu;
+    ev.end_cur = ev.end_prev = ev.pad = 0;
+    ev.appvals = hot >> 24;
+    ev.end_k = 0;
+    ev.out_pos[0] = ev.out_pos[1] = 0;
+    ev.err_pos = 0;
+    return ev;
 }
 
 }  // namespace
@@ -2718,7 +2753,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_syncpick_kernel(ScanParams 
 
 // regular leaf i of capture `cap`, entered in code `in`: simulate the span, record what happened
 __device__ __forceinline__ void emit_simulate(const ScanParams &sp, const LTab &T, uint32_t cap, const uint64_t *edges,
-                                              LeafEvDev *events, uint64_t i, uint32_t in) {
+                                              size_t ev0, uint64_t i, uint32_t in) {
     const uint64_t e_before = edges[i - 1], e_at = edges[i];
     PSim f;
     Acc a;
@@ -2743,7 +2778,7 @@ __device__ __forceinline__ void emit_simulate(const ScanParams &sp, const LTab &
         alive = run_leaf(T, in, span, next_buffer_start(T, e_before), f, a);
         if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
     }
-    write_event(events[i], a, f, alive);
+    put_event(sp, ev0 + i, a, f, alive, false);
 }
 
 // leaves a workgroup of scan_emit_kernel puts aside to simulate together at its end (sync form)
@@ -2801,7 +2836,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                 uint64_t e0;
                 const uint64_t ne = cap_edges(sp.f, cap, e0);
                 const uint64_t *edges = sp.f.edges + e0;
-                LeafEvDev *events = sp.events + e0 + cap;
+                const size_t ev0 = (size_t)e0 + cap;
                 const uint64_t first = 1 + (uint64_t)lb * LB;
                 const uint32_t count = (uint32_t)min((uint64_t)LB, ne - first);
                 // The leaves' entry codes are there already (scan_entry_kernel): no table is staged, nothing goes
@@ -2839,7 +2874,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                         f.cur = to;
                         f.nbits = f.k = 0;
                         f.prev = ((uint32_t)(i & 1ull) ^ T.lvl0) ^ 1u;
-                        write_event(events[i], a, f, true);
+                        put_event(sp, ev0 + i, a, f, true, false);
                     } else {
                         const uint32_t slot = sync_form ? atomicAdd(&s_qn, 1u) : kEmitQueue;
                         if (slot < kEmitQueue) {
@@ -2847,7 +2882,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                             s_q[slot].in = in;
                             s_q[slot].i = i;
                         } else {
-                            emit_simulate(sp, T, cap, edges, events, i, in);
+                            emit_simulate(sp, T, cap, edges, ev0, i, in);
                         }
                     }
                 }
@@ -2857,14 +2892,14 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
             uint64_t e0;
             const uint64_t ne = cap_edges(sp.f, cap, e0);
             const uint64_t *edges = sp.f.edges + e0;
-            LeafEvDev *events = sp.events + e0 + cap;
+            const size_t ev0 = (size_t)e0 + cap;
             if (threadIdx.x == 0) {
                 // first span, from the concrete incoming state
                 PSim f;
                 Acc a;
                 const bool alive = first_leaf(T, sp, edges, ne, f, a);
                 if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
-                write_event(events[0], a, f, alive);
+                put_event(sp, ev0, a, f, alive, ne == 0);
             }
             if (threadIdx.x == 64 && ne > 0) {
                 // tail: the samples after the last edge
@@ -2905,7 +2940,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
                     alive = run_leaf(T, in, tail, next_buffer_start(T, edges[ne - 1]), f, a);
                     if (a.overflow) scan_refuse(sp, cap, (uint32_t)kFbOverflow);
                 }
-                write_event(events[ne], a, f, alive);
+                put_event(sp, ev0 + ne, a, f, alive, true);
             }
             __syncthreads();
         }
@@ -2917,7 +2952,7 @@ __global__ __launch_bounds__(kSimThreads) void scan_emit_kernel(ScanParams sp) {
         const EmitQ e = s_q[j];
         uint64_t e0;
         (void)cap_edges(sp.f, e.cap, e0);
-        emit_simulate(sp, T, e.cap, sp.f.edges + e0, sp.events + e0 + e.cap, e.i, e.in);
+        emit_simulate(sp, T, e.cap, sp.f.edges + e0, (size_t)e0 + e.cap, e.i, e.in);
     }
 }
 
@@ -2995,7 +3030,7 @@ __device__ __forceinline__ void fin_block_scan(const ScanParams &sp, uint32_t ca
     const uint64_t ne = cap_edges(sp.f, cap, e0);
     const uint64_t i = (uint64_t)fb * kFinBlock + threadIdx.x;
     L.have = i <= ne && !(sp.cap_fallback && sp.f.num_captures > 1 && sp.cap_fallback[cap]);
-    if (L.have) L.ev = sp.events[e0 + cap + i];
+    if (L.have) L.ev = get_event(sp, (size_t)e0 + cap + i);
     uint32_t a = L.have ? L.ev.napp : 0u, o = L.have ? L.ev.nout : 0u, e = L.have ? L.ev.nerr : 0u;
     const uint32_t na = a, no = o, nerr = e;
     uint32_t r = 0;
@@ -3748,6 +3783,7 @@ hipError_t launch_fsm_scan(const FsmScanArgs &a, hipStream_t stream, hipEvent_t 
     sp.block_tab = a.block_tab;
     sp.cap_block_off = a.cap_block_off;
     sp.events = a.events;
+    sp.ev_hot = a.ev_hot;
     sp.app_vals = a.app_vals;
     sp.app_capacity = a.app_capacity;
     sp.errs = a.errs;

@@ -356,6 +356,7 @@ struct FsmScanArgs {
     uint32_t *cap_block_off;    // [captures + 1]
     uint32_t total_blocks_cap;
     LeafEvDev *events;          // [edges + captures]
+    uint32_t *ev_hot;           // same count: a leaf's record in one word (the 48-byte one only where it is needed)
     uint8_t *app_vals;          // append pool
     uint64_t app_capacity;
     uint64_t *errs;             // flat error list

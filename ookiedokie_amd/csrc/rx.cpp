@@ -437,6 +437,7 @@ struct ookd_rx {
     DevBuf<uint16_t> d_group_tab, d_super_tab, d_super_in, d_cap_end;
     DevBuf<uint32_t> d_cap_block_off;
     DevBuf<LeafEvDev> d_events;
+    DevBuf<uint32_t> d_ev_hot;
     DevBuf<uint8_t> d_app_vals;
     DevBuf<uint64_t> d_scan_errs;
     DevBuf<SegState> d_final_state;
@@ -524,6 +525,7 @@ struct ookd_rx {
         d_cap_end.release();
         d_cap_block_off.release();
         d_events.release();
+        d_ev_hot.release();
         d_app_vals.release();
         d_scan_errs.release();
         d_final_state.release();
@@ -895,6 +897,7 @@ int ookd_rx::run_pipelined(const void *d_iq) {
         a.cap_block_off = d_cap_block_off.p;
         a.total_blocks_cap = scan_blocks_cap;
         a.events = d_events.p;
+        a.ev_hot = d_ev_hot.p;
         a.app_vals = d_app_vals.p;
         a.app_capacity = d_app_vals.n - 64;
         a.errs = d_scan_errs.p;
@@ -1212,6 +1215,7 @@ int ookd_rx::fsm_scan(const FsmStateDev *first) {
     a.cap_block_off = d_cap_block_off.p;
     a.total_blocks_cap = scan_blocks_cap;
     a.events = d_events.p;
+    a.ev_hot = d_ev_hot.p;
     a.app_vals = d_app_vals.p;
     a.app_capacity = d_app_vals.n - 64;     // fin_msg reads whole 8-byte groups
     a.errs = d_scan_errs.p;
@@ -1829,6 +1833,7 @@ ookd_rx *ookd_rx_create(const ookd_rx_config *cfg, const ookd_filter *filter,
             }
             rc |= rx->d_cap_block_off.alloc(caps + 1);
             rc |= rx->d_events.alloc(rx->edge_capacity + caps + 8);
+            rc |= rx->d_ev_hot.alloc(rx->edge_capacity + caps + 8);
             rc |= rx->d_app_vals.alloc(2 * (rx->edge_capacity + caps) + 512 * caps + 1024);
             rc |= rx->d_scan_errs.alloc(1u << 16);
             rc |= rx->d_cap_fallback.alloc(caps);
